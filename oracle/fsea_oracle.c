@@ -1,0 +1,402 @@
+/*
+ * fsea_oracle.c -- CPU restatement of the frequensea IQ-FFT path (C99, f64).
+ * TEST INFRASTRUCTURE ONLY; see fsea_oracle.h for who may call it and for the
+ * parity-pinning status ("parity unpinned by the reference": no reference
+ * tests exist and FFTW is absent; pinned by definition + independent DFTs).
+ *
+ * Citations are path:line under /root/reference.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "fsea_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ---- a1 ------------------------------------------------------------- */
+
+/* src/nrf.c:100-109: u8i = (u8i + 128) % 256 for HackRF/dummy devices. */
+void orc_flip_u8(const uint8_t *in, uint8_t *out, size_t n_bytes) {
+    for (size_t i = 0; i < n_bytes; i++) {
+        out[i] = (uint8_t)((in[i] + 128) % 256);
+    }
+}
+
+/* ---- a4 ------------------------------------------------------------- */
+
+/* src/nrf.c:601-614.  powf(-1, ii) is exactly +1 for even ii, -1 for odd. */
+void orc_unpack_center_u8(const uint8_t *iq, size_t n_samples, double *out) {
+    for (size_t ii = 0; ii < n_samples; ii++) {
+        double di = iq[2 * ii] / 256.0;
+        double dq = iq[2 * ii + 1] / 256.0;
+        double sign = (ii & 1) ? -1.0 : 1.0;
+        out[2 * ii] = sign * di;
+        out[2 * ii + 1] = sign * dq;
+    }
+}
+
+void orc_unpack_center_f64(const double *iq, size_t n_samples, double *out) {
+    for (size_t ii = 0; ii < n_samples; ii++) {
+        double sign = (ii & 1) ? -1.0 : 1.0;
+        out[2 * ii] = sign * iq[2 * ii];
+        out[2 * ii + 1] = sign * iq[2 * ii + 1];
+    }
+}
+
+/* ---- a5 ------------------------------------------------------------- */
+
+static int ilog2_exact(int n) {
+    int l = 0;
+    if (n < 1) return -1;
+    while ((1 << l) < n) l++;
+    return ((1 << l) == n) ? l : -1;
+}
+
+/* Twiddle table W[k] = exp(-2 pi i k / n), k < n/2, evaluated in long double
+ * and rounded once, so that table error stays at 0.5 ulp. */
+typedef struct {
+    int n;
+    int log2n;
+    double *w;        /* n/2 complex */
+    uint32_t *bitrev; /* n entries */
+} orc_plan;
+
+static int orc_plan_init(orc_plan *p, int n) {
+    int l = ilog2_exact(n);
+    if (l < 0) return -1;
+    p->n = n;
+    p->log2n = l;
+    p->w = (double *)malloc(sizeof(double) * (size_t)(n > 1 ? n : 2));
+    p->bitrev = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    if (!p->w || !p->bitrev) return -1;
+    for (int k = 0; k < n / 2; k++) {
+        long double a = -2.0L * 3.14159265358979323846264338327950288L *
+                        (long double)k / (long double)n;
+        p->w[2 * k] = (double)cosl(a);
+        p->w[2 * k + 1] = (double)sinl(a);
+    }
+    for (int i = 0; i < n; i++) {
+        uint32_t r = 0;
+        for (int b = 0; b < l; b++) {
+            if (i & (1 << b)) r |= 1u << (l - 1 - b);
+        }
+        p->bitrev[i] = r;
+    }
+    return 0;
+}
+
+static void orc_plan_free(orc_plan *p) {
+    free(p->w);
+    free(p->bitrev);
+    p->w = NULL;
+    p->bitrev = NULL;
+}
+
+/* Decimation-in-time radix-2, bit-reversed load, natural-order output. */
+static void orc_plan_exec(const orc_plan *p, const double *in, double *out) {
+    const int n = p->n;
+    for (int i = 0; i < n; i++) {
+        uint32_t r = p->bitrev[i];
+        out[2 * r] = in[2 * i];
+        out[2 * r + 1] = in[2 * i + 1];
+    }
+    for (int half = 1; half < n; half <<= 1) {
+        const int step = n / (2 * half); /* twiddle stride in the n/2 table */
+        for (int base = 0; base < n; base += 2 * half) {
+            for (int k = 0; k < half; k++) {
+                const double wr = p->w[2 * (k * step)];
+                const double wi = p->w[2 * (k * step) + 1];
+                double *a = out + 2 * (base + k);
+                double *b = out + 2 * (base + k + half);
+                const double tr = wr * b[0] - wi * b[1];
+                const double ti = wr * b[1] + wi * b[0];
+                b[0] = a[0] - tr;
+                b[1] = a[1] - ti;
+                a[0] = a[0] + tr;
+                a[1] = a[1] + ti;
+            }
+        }
+    }
+}
+
+int orc_fft_forward(const double *in, double *out, int n) {
+    orc_plan p;
+    if (orc_plan_init(&p, n) != 0) return -1;
+    orc_plan_exec(&p, in, out);
+    orc_plan_free(&p);
+    return 0;
+}
+
+void orc_dft_naive(const double *in, double *out, int n) {
+    const long double tau = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int k = 0; k < n; k++) {
+        long double sr = 0.0L, si = 0.0L;
+        for (int j = 0; j < n; j++) {
+            /* reduce j*k mod n first so the angle stays small and exact */
+            long long m = ((long long)j * (long long)k) % n;
+            long double a = -tau * (long double)m / (long double)n;
+            long double c = cosl(a), s = sinl(a);
+            sr += (long double)in[2 * j] * c - (long double)in[2 * j + 1] * s;
+            si += (long double)in[2 * j] * s + (long double)in[2 * j + 1] * c;
+        }
+        out[2 * k] = (double)sr;
+        out[2 * k + 1] = (double)si;
+    }
+}
+
+/* ---- a7 ------------------------------------------------------------- */
+
+/* src/nrf.c:619-630.  Bin n/2 takes the already computed left neighbour. */
+void orc_mag_row(const double *spectrum, int n, double *row) {
+    for (int i = 0; i < n; i++) {
+        if (i == n / 2 && i > 0) {
+            row[i] = row[i - 1];
+        } else {
+            double fi = spectrum[2 * i];
+            double fq = spectrum[2 * i + 1];
+            row[i] = sqrt(fi * fi + fq * fq);
+        }
+    }
+}
+
+/* ---- a6 / a9 ---------------------------------------------------------- */
+
+/* src/nrf.c:617 (overlapping memcpy in the reference; defined as memmove). */
+void orc_history_scroll(double *history, int n, int h) {
+    if (h > 1) {
+        memmove(history + n, history, sizeof(double) * (size_t)n * (size_t)(h - 1));
+    }
+}
+
+/* src/nrf.c:569-596. */
+void orc_fft_shift(double *history, int n, int h, double d) {
+    int shift_pixels = (int)round(n / d);
+    if (shift_pixels == 0) {
+        return;
+    } else if (abs(shift_pixels) >= n) {
+        memset(history, 0, sizeof(double) * (size_t)n * (size_t)h);
+    } else {
+        for (int y = 0; y < h; y++) {
+            double *row = history + (size_t)y * (size_t)n;
+            if (shift_pixels > 0) {
+                for (int x = 0; x < n - shift_pixels; x++) row[x] = row[x + shift_pixels];
+                for (int x = n - shift_pixels; x < n; x++) row[x] = 0;
+            } else {
+                for (int x = n - 1; x >= -shift_pixels; x--) row[x] = row[x + shift_pixels];
+                for (int x = 0; x < -shift_pixels; x++) row[x] = 0;
+            }
+        }
+    }
+}
+
+/* ---- a11 / a12 -------------------------------------------------------- */
+
+/* c/fft-batch.c:35-37: clamp_u8(int v, min, max); the double -> int
+ * conversion at the call site truncates toward zero (C semantics). */
+static uint8_t orc_clamp_u8(int v, uint8_t lo, uint8_t hi) {
+    return (uint8_t)(v < lo ? lo : v > hi ? hi : v);
+}
+
+void orc_db_u8_row(const double *spectrum, int n, double scale, int dcfix,
+                   uint8_t *row) {
+    for (int x = 0; x < n; x++) {
+        double ci = spectrum[2 * x];
+        double cq = spectrum[2 * x + 1];
+        double pwr = ci * ci + cq * cq;
+        double pwr_dbfs = 10.0 * log10(pwr + 1.0e-20);
+        pwr_dbfs = pwr_dbfs * scale;
+        uint8_t v = orc_clamp_u8((int)pwr_dbfs, 0, 255);
+        if (dcfix && x == n / 2 && x > 0) {
+            v = row[x - 1]; /* c/fft-batch-broad.c:114-116 */
+        }
+        row[x] = v;
+    }
+}
+
+double orc_mean_magnitude(const double *spectrum, size_t count) {
+    double total = 0;
+    for (size_t i = 0; i < count; i++) {
+        double ci = spectrum[2 * i];
+        double cq = spectrum[2 * i + 1];
+        total += sqrt(ci * ci + cq * cq);
+    }
+    return total / (double)count;
+}
+
+/* ---- a14 -------------------------------------------------------------- */
+
+void orc_composite_max(uint8_t *dst, const uint8_t *src, uint32_t dst_x,
+                       uint32_t dst_y, uint32_t src_x, uint32_t src_y,
+                       uint32_t width, uint32_t height, uint32_t dst_stride,
+                       uint32_t src_stride) {
+    for (uint32_t i = 0; i < height; i++) {
+        for (uint32_t j = 0; j < width; j++) {
+            size_t d = (size_t)(dst_y + i) * dst_stride + dst_x + j;
+            size_t s = (size_t)(src_y + i) * src_stride + src_x + j;
+            dst[d] = dst[d] > src[s] ? dst[d] : src[s];
+        }
+    }
+}
+
+/* ---- whole rows --------------------------------------------------------- */
+
+static void orc_one_row(const orc_plan *p, const uint8_t *iq, int flip, int mode,
+                        uint8_t *tmp_u8, double *tmp_in, double *tmp_out,
+                        void *out_row) {
+    const int n = p->n;
+    const uint8_t *src = iq;
+    if (flip) {
+        orc_flip_u8(iq, tmp_u8, (size_t)2 * (size_t)n);
+        src = tmp_u8;
+    }
+    orc_unpack_center_u8(src, (size_t)n, tmp_in);
+    orc_plan_exec(p, tmp_in, tmp_out);
+    switch (mode) {
+    case 0:
+        orc_mag_row(tmp_out, n, (double *)out_row);
+        break;
+    case 1:
+        orc_db_u8_row(tmp_out, n, 10.0, 0, (uint8_t *)out_row);
+        break;
+    case 2:
+        orc_db_u8_row(tmp_out, n, 5.0, 1, (uint8_t *)out_row);
+        break;
+    case 3:
+        memcpy(out_row, tmp_out, sizeof(double) * 2 * (size_t)n);
+        break;
+    case 4: {
+        double *row = (double *)out_row;
+        for (int i = 0; i < n; i++) {
+            row[i] = sqrt(tmp_out[2 * i] * tmp_out[2 * i] + tmp_out[2 * i + 1] * tmp_out[2 * i + 1]);
+        }
+        break;
+    }
+    case 5: {
+        double *row = (double *)out_row;
+        for (int i = 0; i < n; i++) {
+            double pwr = tmp_out[2 * i] * tmp_out[2 * i] + tmp_out[2 * i + 1] * tmp_out[2 * i + 1];
+            row[i] = 10.0 * log10(pwr + 1.0e-20);
+        }
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+int orc_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip,
+             int mode, void *out) {
+    orc_plan p;
+    if (mode < 0 || mode > 5) return -2;
+    if (orc_plan_init(&p, n) != 0) return -1;
+    uint8_t *tmp_u8 = (uint8_t *)malloc((size_t)2 * (size_t)n);
+    double *tmp_in = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tmp_out = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    size_t row_bytes = (mode == 1 || mode == 2) ? (size_t)n
+                       : (mode == 3)            ? sizeof(double) * 2 * (size_t)n
+                                                : sizeof(double) * (size_t)n;
+    for (size_t f = 0; f < n_frames; f++) {
+        orc_one_row(&p, iq + 2 * f * hop, flip, mode, tmp_u8, tmp_in, tmp_out,
+                    (uint8_t *)out + f * row_bytes);
+    }
+    free(tmp_u8);
+    free(tmp_in);
+    free(tmp_out);
+    orc_plan_free(&p);
+    return 0;
+}
+
+/* ---- cpu_baseline ("port") ---------------------------------------------- */
+
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double orc_time_mag_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop,
+                         double *sink) {
+    orc_plan p;
+    if (orc_plan_init(&p, n) != 0) return -1.0;
+    uint8_t *tmp_u8 = (uint8_t *)malloc((size_t)2 * (size_t)n);
+    double *tmp_in = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tmp_out = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *row = (double *)malloc(sizeof(double) * (size_t)n);
+    double t0 = now_seconds();
+    for (size_t f = 0; f < n_frames; f++) {
+        orc_one_row(&p, iq + 2 * f * hop, 1, 0, tmp_u8, tmp_in, tmp_out, row);
+    }
+    double t1 = now_seconds();
+    if (sink) memcpy(sink, row, sizeof(double) * (size_t)n);
+    free(tmp_u8);
+    free(tmp_in);
+    free(tmp_out);
+    free(row);
+    orc_plan_free(&p);
+    return t1 - t0;
+}
+
+typedef struct {
+    const uint8_t *iq;
+    size_t f0, f1;
+    int n;
+    size_t hop;
+    double checksum;
+} orc_mt_job;
+
+static void *orc_mt_worker(void *arg) {
+    orc_mt_job *job = (orc_mt_job *)arg;
+    orc_plan p;
+    if (orc_plan_init(&p, job->n) != 0) return NULL;
+    const int n = job->n;
+    uint8_t *tmp_u8 = (uint8_t *)malloc((size_t)2 * (size_t)n);
+    double *tmp_in = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tmp_out = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *row = (double *)malloc(sizeof(double) * (size_t)n);
+    double acc = 0;
+    for (size_t f = job->f0; f < job->f1; f++) {
+        orc_one_row(&p, job->iq + 2 * f * job->hop, 1, 0, tmp_u8, tmp_in, tmp_out, row);
+        acc += row[1];
+    }
+    job->checksum = acc;
+    free(tmp_u8);
+    free(tmp_in);
+    free(tmp_out);
+    free(row);
+    orc_plan_free(&p);
+    return NULL;
+}
+
+/* Frames sharded over n_threads pthreads, one plan per thread (BASELINE.md
+ * section 4, item 2 (ii)).  Returns wall seconds. */
+double orc_time_mag_rows_mt(const uint8_t *iq, size_t n_frames, int n, size_t hop,
+                            int n_threads, double *checksum) {
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    orc_mt_job *jobs = (orc_mt_job *)calloc((size_t)n_threads, sizeof(orc_mt_job));
+    double t0 = now_seconds();
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].iq = iq;
+        jobs[t].n = n;
+        jobs[t].hop = hop;
+        jobs[t].f0 = n_frames * (size_t)t / (size_t)n_threads;
+        jobs[t].f1 = n_frames * (size_t)(t + 1) / (size_t)n_threads;
+        pthread_create(&th[t], NULL, orc_mt_worker, &jobs[t]);
+    }
+    double acc = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        acc += jobs[t].checksum;
+    }
+    double t1 = now_seconds();
+    if (checksum) *checksum = acc;
+    free(th);
+    free(jobs);
+    return t1 - t0;
+}

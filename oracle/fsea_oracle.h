@@ -1,0 +1,108 @@
+/*
+ * fsea_oracle.h -- CPU restatement (C99, double precision) of the frequensea
+ * IQ-FFT spectrum path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call this library.  The product (libfsea_hip.so / libfsea_nrf.so)
+ * never does: it has no CPU fallback and fails loudly without a GPU.
+ *
+ * PARITY PINNING STATUS: "parity unpinned by the reference".  The reference
+ * ships no tests / golden vectors and its FFT arithmetic
+ * lives in FFTW3 (double precision, version unpinned: CMakeLists.txt:16,
+ * README.md:19,23), which is absent from /root/reference and from this
+ * image; src/nrf.c cannot be compiled here without stand-ins for
+ * fftw3.h / libhackrf / rtl-sdr / OpenAL headers, so it is treated as
+ * unbuildable.  What pins this oracle instead:
+ *   - FFTW's published definition of fftw_plan_dft_1d(FFTW_FORWARD):
+ *     unnormalised X[k] = sum_j x[j] exp(-2 pi i j k / N);
+ *   - an O(N^2) long-double DFT in this file (orc_dft_naive);
+ *   - scipy/pocketfft on the reference's recorded rfdata captures
+ *     (tests/golden/make_golden.py, committed fixtures);
+ *   - the known-answer values SURVEY.md section 8(c) recorded from the
+ *     reference's own nrf.c;
+ *   - oracle/_ref/libnut_ref.so = the reference's src/nut.c compiled as is
+ *     (it needs no third-party headers) pins the nut_buffer conventions.
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference).
+ */
+#ifndef FSEA_ORACLE_H
+#define FSEA_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a1: HackRF int8 -> offset binary.  src/nrf.c:100-109, c/fft-batch.c:63-64 */
+void orc_flip_u8(const uint8_t *in, uint8_t *out, size_t n_bytes);
+
+/* a4: u8 interleaved IQ -> complex double with (-1)^n centring.
+ * src/nrf.c:601-614 (U8 branch: u8/256.0). out has 2*n_samples doubles. */
+void orc_unpack_center_u8(const uint8_t *iq, size_t n_samples, double *out);
+
+/* a4, F64 branch: src/nrf.c:607-612. */
+void orc_unpack_center_f64(const double *iq, size_t n_samples, double *out);
+
+/* a5: unnormalised forward DFT, -1 exponent (what fftw_execute does for the
+ * plan made at src/nrf.c:564 / c/fft-batch.c:144).  n must be a power of 2.
+ * in/out: interleaved re,im doubles; out-of-place. Returns 0, or -1 on bad n. */
+int orc_fft_forward(const double *in, double *out, int n);
+
+/* Same transform as an O(n^2) long-double sum; any n >= 1.  Self-check only. */
+void orc_dft_naive(const double *in, double *out, int n);
+
+/* a7: magnitude row + DC compensation.  src/nrf.c:619-630.
+ * row[i] = sqrt(re^2+im^2); row[n/2] = row[n/2-1]. */
+void orc_mag_row(const double *spectrum, int n, double *row);
+
+/* a6: history scroll (rows 0..h-2 -> 1..h-1), defined as memmove.
+ * src/nrf.c:616-617. */
+void orc_history_scroll(double *history, int n, int h);
+
+/* a9: nrf_fft_shift.  src/nrf.c:569-596. */
+void orc_fft_shift(double *history, int n, int h, double d);
+
+/* a11/a12: dB pixel row.  c/fft-batch.c:83-94 (scale 10, dcfix 0),
+ * c/fft-batch-broad.c:106-121 (scale 5, dcfix 1). */
+void orc_db_u8_row(const double *spectrum, int n, double scale, int dcfix,
+                   uint8_t *row);
+
+/* a12: mean magnitude over count complex bins. c/fft-batch-broad.c:81-98.
+ * The reference skips the frequency when the mean is < 1.1. */
+double orc_mean_magnitude(const double *spectrum, size_t count);
+
+/* a14: max-composite of a w x h tile into dst at (dst_x, dst_y).
+ * c/fft-stitch.c:46-54, c/fft-stitch-broad.c:28-36. */
+void orc_composite_max(uint8_t *dst, const uint8_t *src, uint32_t dst_x,
+                       uint32_t dst_y, uint32_t src_x, uint32_t src_y,
+                       uint32_t width, uint32_t height, uint32_t dst_stride,
+                       uint32_t src_stride);
+
+/* Whole-row pipelines (flip? -> unpack -> FFT -> epilogue), frame f starts at
+ * sample f*hop of `iq`.  mode: 0 = MAG (a7), 1 = DB10_U8 (a11),
+ * 2 = DB5_U8_DCFIX (a12), 3 = complex spectrum (a5 only, 2n doubles/row),
+ * 4 = MAG without the DC patch, 5 = 10*log10(pwr + 1e-20) as double.
+ * out is double[n_frames*n] for modes 0,4,5, uint8_t[n_frames*n] for 1,2,
+ * double[n_frames*2n] for 3.  Returns 0 on success. */
+int orc_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip,
+             int mode, void *out);
+
+/* The reference-shaped per-frame loop used as bench.py's cpu_baseline
+ * ("port"): a1 flip -> a4 unpack (n samples) -> a5 FFT -> a7 magnitude, on
+ * one core, with a pre-planned twiddle table.  Returns seconds elapsed for
+ * n_frames frames (monotonic clock); sink receives the last row. */
+double orc_time_mag_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop,
+                         double *sink);
+
+/* Same loop with frames sharded over n_threads pthreads, one plan per thread
+ * (BASELINE.md section 4 item 2(ii)).  Returns wall seconds. */
+double orc_time_mag_rows_mt(const uint8_t *iq, size_t n_frames, int n, size_t hop,
+                            int n_threads, double *checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

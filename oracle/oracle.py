@@ -1,0 +1,183 @@
+"""ctypes view of the CPU oracle (oracle/libfsea_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product never imports this module.
+Parity status: see oracle/fsea_oracle.h ("parity unpinned by the reference").
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MODE_MAG = 0
+MODE_DB10_U8 = 1
+MODE_DB5_U8_DCFIX = 2
+MODE_COMPLEX = 3
+MODE_MAG_NODC = 4
+MODE_DB_F64 = 5
+
+
+def build():
+    """Compile the oracle (and oracle/_ref when /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libfsea_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        c_u8p = ctypes.POINTER(ctypes.c_uint8)
+        c_f64p = ctypes.POINTER(ctypes.c_double)
+        L.orc_flip_u8.argtypes = [c_u8p, c_u8p, ctypes.c_size_t]
+        L.orc_flip_u8.restype = None
+        L.orc_unpack_center_u8.argtypes = [c_u8p, ctypes.c_size_t, c_f64p]
+        L.orc_unpack_center_u8.restype = None
+        L.orc_unpack_center_f64.argtypes = [c_f64p, ctypes.c_size_t, c_f64p]
+        L.orc_unpack_center_f64.restype = None
+        L.orc_fft_forward.argtypes = [c_f64p, c_f64p, ctypes.c_int]
+        L.orc_fft_forward.restype = ctypes.c_int
+        L.orc_dft_naive.argtypes = [c_f64p, c_f64p, ctypes.c_int]
+        L.orc_dft_naive.restype = None
+        L.orc_mag_row.argtypes = [c_f64p, ctypes.c_int, c_f64p]
+        L.orc_mag_row.restype = None
+        L.orc_history_scroll.argtypes = [c_f64p, ctypes.c_int, ctypes.c_int]
+        L.orc_history_scroll.restype = None
+        L.orc_fft_shift.argtypes = [c_f64p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.orc_fft_shift.restype = None
+        L.orc_db_u8_row.argtypes = [c_f64p, ctypes.c_int, ctypes.c_double, ctypes.c_int, c_u8p]
+        L.orc_db_u8_row.restype = None
+        L.orc_mean_magnitude.argtypes = [c_f64p, ctypes.c_size_t]
+        L.orc_mean_magnitude.restype = ctypes.c_double
+        L.orc_composite_max.argtypes = [c_u8p, c_u8p] + [ctypes.c_uint32] * 8
+        L.orc_composite_max.restype = None
+        L.orc_rows.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.orc_rows.restype = ctypes.c_int
+        L.orc_time_mag_rows.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, c_f64p]
+        L.orc_time_mag_rows.restype = ctypes.c_double
+        L.orc_time_mag_rows_mt.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t,
+                                           ctypes.c_int, c_f64p]
+        L.orc_time_mag_rows_mt.restype = ctypes.c_double
+        _LIB = L
+    return _LIB
+
+
+def _u8p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def _f64p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def flip_u8(raw):
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    out = np.empty_like(raw)
+    lib().orc_flip_u8(_u8p(raw), _u8p(out), raw.size)
+    return out
+
+
+def unpack_center_u8(iq_u8):
+    iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8)
+    n = iq_u8.size // 2
+    out = np.empty(2 * n, dtype=np.float64)
+    lib().orc_unpack_center_u8(_u8p(iq_u8), n, _f64p(out))
+    return out.view(np.complex128)
+
+
+def unpack_center_f64(iq_f64):
+    iq_f64 = np.ascontiguousarray(iq_f64, dtype=np.float64)
+    n = iq_f64.size // 2
+    out = np.empty(2 * n, dtype=np.float64)
+    lib().orc_unpack_center_f64(_f64p(iq_f64), n, _f64p(out))
+    return out.view(np.complex128)
+
+
+def fft_forward(x):
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    out = np.empty_like(x)
+    rc = lib().orc_fft_forward(_f64p(x.view(np.float64)), _f64p(out.view(np.float64)), x.size)
+    if rc != 0:
+        raise ValueError("orc_fft_forward: n must be a power of two")
+    return out
+
+
+def dft_naive(x):
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    out = np.empty_like(x)
+    lib().orc_dft_naive(_f64p(x.view(np.float64)), _f64p(out.view(np.float64)), x.size)
+    return out
+
+
+def mag_row(spectrum):
+    s = np.ascontiguousarray(spectrum, dtype=np.complex128)
+    out = np.empty(s.size, dtype=np.float64)
+    lib().orc_mag_row(_f64p(s.view(np.float64)), s.size, _f64p(out))
+    return out
+
+
+def history_scroll(history, n, h):
+    assert history.dtype == np.float64 and history.flags.c_contiguous
+    lib().orc_history_scroll(_f64p(history), n, h)
+
+
+def fft_shift(history, n, h, d):
+    assert history.dtype == np.float64 and history.flags.c_contiguous
+    lib().orc_fft_shift(_f64p(history), n, h, float(d))
+
+
+def db_u8_row(spectrum, scale, dcfix):
+    s = np.ascontiguousarray(spectrum, dtype=np.complex128)
+    out = np.empty(s.size, dtype=np.uint8)
+    lib().orc_db_u8_row(_f64p(s.view(np.float64)), s.size, float(scale), int(dcfix), _u8p(out))
+    return out
+
+
+def mean_magnitude(spectrum):
+    s = np.ascontiguousarray(spectrum, dtype=np.complex128).ravel()
+    return lib().orc_mean_magnitude(_f64p(s.view(np.float64)), s.size)
+
+
+def composite_max(dst, src, dst_x, dst_y=0):
+    assert dst.dtype == np.uint8 and src.dtype == np.uint8
+    assert dst.flags.c_contiguous and src.flags.c_contiguous
+    h, w = src.shape
+    lib().orc_composite_max(_u8p(dst), _u8p(src), dst_x, dst_y, 0, 0, w, h, dst.shape[1], w)
+
+
+def rows(iq, n_frames, n, hop=None, flip=True, mode=MODE_MAG):
+    """Whole rows: frame f = samples [f*hop, f*hop+n) of the u8 IQ stream."""
+    hop = n if hop is None else hop
+    iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
+    need = 2 * ((n_frames - 1) * hop + n) if n_frames else 0
+    if iq.size < need:
+        raise ValueError("iq too short: %d < %d" % (iq.size, need))
+    if mode in (MODE_DB10_U8, MODE_DB5_U8_DCFIX):
+        out = np.empty((n_frames, n), dtype=np.uint8)
+    elif mode == MODE_COMPLEX:
+        out = np.empty((n_frames, n), dtype=np.complex128)
+    else:
+        out = np.empty((n_frames, n), dtype=np.float64)
+    rc = lib().orc_rows(_u8p(iq), n_frames, n, hop, int(bool(flip)), mode,
+                        out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise ValueError("orc_rows failed: %d" % rc)
+    return out
+
+
+def time_mag_rows(iq, n_frames, n, hop=None, threads=1):
+    """cpu_baseline leg: seconds for n_frames reference-shaped rows."""
+    hop = n if hop is None else hop
+    iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
+    if threads <= 1:
+        sink = np.empty(n, dtype=np.float64)
+        return lib().orc_time_mag_rows(_u8p(iq), n_frames, n, hop, _f64p(sink))
+    chk = ctypes.c_double(0)
+    return lib().orc_time_mag_rows_mt(_u8p(iq), n_frames, n, hop, threads, ctypes.byref(chk))

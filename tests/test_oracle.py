@@ -1,0 +1,177 @@
+"""CPU: pin the C oracle against the golden vectors, analytic known answers and
+the values SURVEY.md 8(c) recorded from the reference's own nrf.c."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, ROOT
+
+
+def test_flip_identity_all_bytes():
+    b = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(O.flip_u8(b), b ^ 0x80)          # (b+128)%256 == b^0x80
+    assert np.array_equal(O.flip_u8(b), ((b.astype(int) + 128) % 256).astype(np.uint8))
+
+
+@pytest.mark.parametrize("key", GOLDEN_KEYS)
+def test_flip_golden(golden, key):
+    assert np.array_equal(O.flip_u8(golden[key + "__raw"]), golden[key + "__flipped"])
+
+
+def test_survey_known_answers(golden):
+    """values reproduced from the reference's nrf.c."""
+    raw = golden["rf_100p900_1__raw"]
+    assert list(O.flip_u8(raw[:8])) == [113, 148, 103, 117, 119, 111, 140, 123]
+    row = O.rows(raw, 1, 1024)[0]
+    np.testing.assert_allclose(row[:4], [0.155516, 0.194782, 0.178461, 0.141473], atol=5e-7)
+    assert row.argmax() == 513
+    assert abs(row.max() - 37.935861) < 1e-6
+    assert abs(row.sum() - 1567.312172) < 1e-6
+    spec = O.rows(raw, 1, 1024, mode=O.MODE_COMPLEX)[0]
+    assert abs(abs(spec[512]) - 728.425422) < 1e-6
+    row = O.rows(raw, 1, 8192)[0]
+    assert row.argmax() == 3358 and abs(row.max() - 162.437851) < 1e-6
+    assert abs(row.sum() - 29851.896936) < 1e-5
+    row = O.rows(golden["rf_202p500_2__raw"], 1, 1024)[0]
+    assert row.argmax() == 666 and abs(row.max() - 255.674368) < 1e-6
+    assert abs(row.sum() - 1669.595959) < 1e-6
+
+
+@pytest.mark.parametrize("key", GOLDEN_KEYS)
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
+def test_rows_match_golden(golden, key, n):
+    raw = golden[key + "__raw"]
+    want = golden["%s__mag_%d" % (key, n)]
+    got = O.rows(raw, 1, n)[0]
+    # two independent double FFTs: agreement to ~1e-12 relative to the row scale
+    assert np.max(np.abs(got - want)) <= 1e-11 * max(1.0, want.max())
+    assert got[n // 2] == got[n // 2 - 1]
+    for mode, name in [(O.MODE_DB10_U8, "db10"), (O.MODE_DB5_U8_DCFIX, "db5")]:
+        wantp = golden["%s__%s_%d" % (key, name, n)]
+        gotp = O.rows(raw, 1, n, mode=mode)[0]
+        diff = np.abs(gotp.astype(int) - wantp.astype(int))
+        assert diff.max() <= 1 and np.count_nonzero(diff) <= max(1, n // 1000)
+
+
+@pytest.mark.parametrize("key", GOLDEN_KEYS[:2])
+@pytest.mark.parametrize("n", [128, 256, 1024])
+def test_spectrum_matches_golden_and_naive(golden, key, n):
+    raw = golden[key + "__raw"]
+    spec = O.rows(raw, 1, n, mode=O.MODE_COMPLEX)[0]
+    want = golden["%s__spec_%d" % (key, n)]
+    assert np.max(np.abs(spec - want)) <= 1e-11 * np.abs(want).max()
+    x = O.unpack_center_u8(O.flip_u8(raw[: 2 * n]))
+    naive = O.dft_naive(x)
+    assert np.max(np.abs(spec - naive)) <= 1e-11 * np.abs(naive).max()
+
+
+def test_unpack_center_exact():
+    u = np.arange(256, dtype=np.uint8).repeat(2)          # I=Q=k for sample k
+    x = O.unpack_center_u8(u)
+    k = np.arange(256)
+    sign = np.where(k % 2 == 0, 1.0, -1.0)
+    assert np.array_equal(x.real, sign * k / 256.0) and np.array_equal(x.imag, sign * k / 256.0)
+    f = np.linspace(-1, 1, 64)
+    y = O.unpack_center_f64(f)
+    assert np.array_equal(y.real, f[0::2] * np.where(np.arange(32) % 2 == 0, 1, -1))
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 64, 512, 2048])
+def test_fft_analytic(n):
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=n) + 1j * rng.normal(size=n)
+    X = O.fft_forward(x)
+    assert np.allclose(X, np.fft.fft(x), rtol=0, atol=1e-11 * n)
+    # impulse -> flat spectrum
+    imp = np.zeros(n, complex); imp[0] = 0.75
+    assert np.allclose(O.fft_forward(imp), 0.75)
+    # Parseval
+    assert abs(np.sum(np.abs(X) ** 2) - n * np.sum(np.abs(x) ** 2)) < 1e-9 * n * n
+    # linearity
+    y = rng.normal(size=n) + 1j * rng.normal(size=n)
+    assert np.allclose(O.fft_forward(2 * x - 3j * y), 2 * X - 3j * O.fft_forward(y), atol=1e-10 * n)
+    with pytest.raises(ValueError):
+        O.fft_forward(np.zeros(3, complex))
+
+
+def test_constant_input_dc_patch():
+    n = 1024
+    raw = np.zeros(2 * n, dtype=np.uint8)                  # int8 0 -> u8 128 after flip
+    spec = O.rows(raw, 1, n, mode=O.MODE_COMPLEX)[0]
+    assert abs(abs(spec[n // 2]) - 0.5 * n * np.sqrt(2)) < 1e-9
+    others = np.delete(np.abs(spec), n // 2)
+    assert others.max() < 1e-9
+    row = O.rows(raw, 1, n)[0]
+    assert row.max() < 1e-9                                # DC never reaches the output
+
+
+def test_tone_lands_at_shifted_bin():
+    n, k0 = 1024, 100
+    t = np.arange(n)
+    z = 40 * np.exp(2j * np.pi * k0 * t / n)
+    raw = np.empty(2 * n, dtype=np.int8)
+    raw[0::2] = np.rint(z.real); raw[1::2] = np.rint(z.imag)
+    row = O.rows(raw.view(np.uint8), 1, n)[0]
+    assert row.argmax() == (k0 + n // 2) % n
+
+
+def test_history_scroll_and_shift(golden):
+    hist = golden["shift__history"].copy()
+    n, h = hist.shape[1], hist.shape[0]
+    scrolled = hist.copy()
+    O.history_scroll(scrolled, n, h)
+    assert np.array_equal(scrolled[1:], hist[:-1]) and np.array_equal(scrolled[0], hist[0])
+    for name in ["p8", "m8", "half", "p50", "m3", "big", "mhalf"]:
+        d = float(golden["shift__" + name + "__d"][0])
+        got = hist.copy()
+        O.fft_shift(got, n, h, d)
+        assert np.array_equal(got, golden["shift__" + name]), name
+
+
+def test_db_rows_truncate_and_clamp():
+    spec = np.array([0, 1, 10, 1e3, 1e13, 10 ** 1.26, 10 ** (25.5 / 20)], dtype=complex)
+    px = O.db_u8_row(spec, 10.0, 0)
+    # 0 -> 10*log10(1e-20)*10 = -2000 -> 0 ; 1 -> 0 ; 10 -> 200 ; 1e3 -> 600 -> 255
+    assert list(px[:5]) == [0, 0, 200, 255, 255]
+    assert px[5] == 252 and px[6] in (254, 255)
+    px5 = O.db_u8_row(np.array([1, 10, 100, 1000], complex), 5.0, 1)
+    assert list(px5) == [0, 100, 100, 255]               # pixel n/2 (=2) copies pixel 1
+
+
+def test_mean_magnitude_gate():
+    spec = np.full(100 * 256, 1.0 + 0j)
+    assert abs(O.mean_magnitude(spec) - 1.0) < 1e-12     # < 1.1 -> "not interesting"
+    assert O.mean_magnitude(spec * 2) > 1.1
+
+
+def test_composite_max():
+    dst = np.zeros((4, 12), np.uint8)
+    a = np.arange(32, dtype=np.uint8).reshape(4, 8)
+    O.composite_max(dst, a, 0)
+    O.composite_max(dst, (31 - a).astype(np.uint8), 4)     # 50 % overlap
+    want = np.zeros((4, 12), np.uint8)
+    want[:, :8] = a
+    want[:, 4:] = np.maximum(want[:, 4:], 31 - a)
+    assert np.array_equal(dst, want)
+
+
+def test_reference_nut_conventions():
+    """oracle/_ref/libnut_ref.so is the reference's own src/nut.c (built by
+    oracle/Makefile when /root/reference exists): u8<->f64 is /256.0, *256.0."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libnut_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (reference absent)")
+    L = ctypes.CDLL(path)
+    L.nut_buffer_new_u8.restype = ctypes.c_void_p
+    L.nut_buffer_new_u8.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.nut_buffer_get_f64.restype = ctypes.c_double
+    L.nut_buffer_get_f64.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.nut_buffer_free.argtypes = [ctypes.c_void_p]
+    data = np.arange(256, dtype=np.uint8)
+    buf = L.nut_buffer_new_u8(128, 2, data.ctypes.data)
+    for k in (0, 1, 128, 255):
+        assert L.nut_buffer_get_f64(buf, k) == k / 256.0
+    L.nut_buffer_free(buf)
