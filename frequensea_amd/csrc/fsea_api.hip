@@ -1,0 +1,461 @@
+// fsea_api.hip -- the C ABI of libfsea_hip.so (see include/fsea.h).
+//
+// Host-side plan management around the kernels of fsea_fft_core.h: twiddle
+// tables, persistent-grid sizing, launches, and the two small helper kernels
+// (tile max-composite, mean-magnitude reduction).  No CPU compute path exists
+// here: if HIP cannot give us a device, plan creation fails.
+#include "../../include/fsea.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fsea_registry.h"
+#include "fsea_tables.h"
+
+extern "C" int fsea_kernels_small(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_1024(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_2048(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_4096(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_8192(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_16384(fsea::KernelEntry *out, int cap);
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define FSEA_HIP(call)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            return fail(FSEA_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                \
+        }                                                                                         \
+    } while (0)
+
+const std::vector<fsea::KernelEntry> &registry() {
+    static std::vector<fsea::KernelEntry> all = [] {
+        std::vector<fsea::KernelEntry> v;
+        fsea::KernelEntry tmp[32];
+        int (*lists[])(fsea::KernelEntry *, int) = {fsea_kernels_small, fsea_kernels_1024, fsea_kernels_2048,
+                                                    fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384};
+        for (auto fn : lists) {
+            int n = fn(tmp, 32);
+            for (int i = 0; i < n; ++i) v.push_back(tmp[i]);
+        }
+        return v;
+    }();
+    return all;
+}
+
+const fsea::KernelEntry *find_entry(int n, const char *variant) {
+    for (const auto &e : registry()) {
+        if (e.n == n && std::strcmp(e.variant, variant ? variant : "") == 0) return &e;
+    }
+    return nullptr;
+}
+
+size_t mode_elem_bytes(int mode) {
+    switch (mode) {
+    case FSEA_MODE_DB10_U8:
+    case FSEA_MODE_DB5_U8_DCFIX:
+        return 1;
+    case FSEA_MODE_COMPLEX_F32:
+        return 8;
+    default:
+        return 4;
+    }
+}
+
+__global__ void fsea_composite_max_kernel(uint8_t *dst, const uint8_t *src, uint32_t dst_x, uint32_t dst_y,
+                                          uint32_t width, uint32_t height, uint32_t dst_stride,
+                                          uint32_t src_stride) {
+    // one thread per 4 horizontally adjacent pixels; rows by blockIdx.y
+    const uint32_t x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (uint32_t y = blockIdx.y; y < height; y += gridDim.y) {
+        if (x4 >= width) return;
+        uint8_t *d = dst + (size_t)(dst_y + y) * dst_stride + dst_x + x4;
+        const uint8_t *s = src + (size_t)y * src_stride + x4;
+        const bool vec = (x4 + 4 <= width) && ((reinterpret_cast<uintptr_t>(d) & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(s) & 3) == 0);
+        if (vec) {
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(d);
+            const uint32_t b = *reinterpret_cast<const uint32_t *>(s);
+            uint32_t r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t ab = (a >> (8 * k)) & 0xff, bb = (b >> (8 * k)) & 0xff;
+                r |= (ab > bb ? ab : bb) << (8 * k);
+            }
+            *reinterpret_cast<uint32_t *>(d) = r;
+        } else {
+            for (uint32_t k = 0; k < 4 && x4 + k < width; ++k) d[k] = d[k] > s[k] ? d[k] : s[k];
+        }
+    }
+}
+
+__global__ void fsea_sum_f32_kernel(const float *x, size_t n, double *acc) {
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        s += (double)x[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) part[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += part[i];
+        atomicAdd(acc, tot);
+    }
+}
+
+__global__ void fsea_f64_to_f32_kernel(const double *in, float *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        out[i] = (float)in[i];
+    }
+}
+
+}  // namespace
+
+struct fsea_plan {
+    int n = 0;
+    int hop = 0;
+    int mode = 0;
+    int device = 0;
+    const fsea::KernelEntry *entry = nullptr;
+    hipStream_t stream = nullptr;
+    float2 *d_tw = nullptr;       // passes 1..np-1 concatenated
+    size_t tw_off[4] = {0, 0, 0, 0};
+    int num_cu = 0;
+    int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0;
+    // staging for the host-buffer entry points
+    std::mutex mu;
+    void *d_in = nullptr;
+    size_t d_in_bytes = 0;
+    void *d_out = nullptr;
+    size_t d_out_bytes = 0;
+    void *d_aux = nullptr;
+    size_t d_aux_bytes = 0;
+    double *d_acc = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string kernel_name;
+};
+
+namespace {
+
+int ensure(void **ptr, size_t *cap, size_t need) {
+    if (*cap >= need) return FSEA_OK;
+    if (*ptr) {
+        FSEA_HIP(hipFree(*ptr));
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    size_t want = need + need / 4 + 4096;
+    FSEA_HIP(hipMalloc(ptr, want));
+    *cap = want;
+    return FSEA_OK;
+}
+
+unsigned grid_for(const fsea_plan *p, int occ, size_t n_frames) {
+    const size_t units = (n_frames + p->entry->fpw - 1) / p->entry->fpw;
+    size_t g = (size_t)p->num_cu * (size_t)(occ > 0 ? occ : 1);
+    if (units < g) g = units;
+    if (g >= 8) g &= ~(size_t)7;  // the kernel's XCD-aware frame mapping wants a multiple of 8
+    if (g == 0) g = 1;
+    return (unsigned)g;
+}
+
+int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
+           hipStream_t s) {
+    if (n_frames == 0) return FSEA_OK;
+    fsea::FftArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.n_frames = n_frames;
+    a.hop = (size_t)p->hop;
+    a.xormask = flip ? 0u : 0x80808080u;
+    a.mode = mode;
+    for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
+    const int occ = (in_kind == fsea::IN_F32) ? p->occ_f32 : (mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8);
+    p->entry->launch(in_kind, a, grid_for(p, occ, n_frames), s);
+    FSEA_HIP(hipGetLastError());
+    return FSEA_OK;
+}
+
+int check_exec_args(const fsea_plan *plan, const void *in, const void *out, size_t align) {
+    if (!plan) return fail(FSEA_EINVAL, "plan is NULL");
+    if (!in || !out) return fail(FSEA_EINVAL, "NULL buffer");
+    if (reinterpret_cast<uintptr_t>(in) % align) return fail(FSEA_EINVAL, "input pointer must be %zu-byte aligned", align);
+    if (reinterpret_cast<uintptr_t>(out) % 16) return fail(FSEA_EINVAL, "output pointer must be 16-byte aligned");
+    return FSEA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fsea_last_error_string(void) { return g_last_error.c_str(); }
+
+int fsea_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    if (e != hipSuccess || n <= 0) return fail(FSEA_ENODEVICE, "no HIP device: %s", hipGetErrorString(e));
+    return FSEA_OK;
+}
+
+int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, int device, const char *variant) {
+    if (!out) return fail(FSEA_EINVAL, "plan out-pointer is NULL");
+    *out = nullptr;
+    if (mode < FSEA_MODE_MAG_F32 || mode > FSEA_MODE_DB_F32) return fail(FSEA_EINVAL, "unknown mode %d", mode);
+    const fsea::KernelEntry *e = find_entry(fft_size, variant);
+    if (!e) {
+        return fail(FSEA_EINVAL, "unsupported fft_size %d (variant '%s'): power of two in [128, 16384] required",
+                    fft_size, variant ? variant : "");
+    }
+    if (hop <= 0 || (hop % 8) != 0) return fail(FSEA_EINVAL, "hop must be a positive multiple of 8 (got %d)", hop);
+    int count = 0;
+    hipError_t ce = hipGetDeviceCount(&count);
+    if (ce != hipSuccess || count <= 0) {
+        return fail(FSEA_ENODEVICE, "no HIP device available (%s); libfsea_hip has no CPU fallback",
+                    hipGetErrorString(ce));
+    }
+    if (device < 0 || device >= count) return fail(FSEA_EINVAL, "device %d out of range [0,%d)", device, count);
+    FSEA_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FSEA_HIP(hipGetDeviceProperties(&prop, device));
+
+    fsea_plan *p = new (std::nothrow) fsea_plan();
+    if (!p) return fail(FSEA_ENOMEM, "out of host memory");
+    p->n = fft_size;
+    p->hop = hop;
+    p->mode = mode;
+    p->device = device;
+    p->entry = e;
+    p->num_cu = prop.multiProcessorCount;
+    p->kernel_name = (mode == FSEA_MODE_MAG_F32) ? e->name_u8_mag : e->name_u8;
+
+    std::vector<fsea::TwPair> tw;
+    fsea::build_twiddles(e->np, e->radix, tw, p->tw_off);
+    static_assert(sizeof(fsea::TwPair) == sizeof(float2), "twiddle layout");
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&p->d_tw), tw.size() * sizeof(float2));
+    if (he == hipSuccess) he = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_acc), sizeof(double));
+    if (he == hipSuccess) he = hipEventCreate(&p->ev0);
+    if (he == hipSuccess) he = hipEventCreate(&p->ev1);
+    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8_mag, e->fn_u8_mag, e->wg, 0);
+    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8, e->fn_u8, e->wg, 0);
+    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_f32, e->fn_f32, e->wg, 0);
+    if (he != hipSuccess) {
+        int rc = fail(FSEA_EHIP, "plan setup failed: %s", hipGetErrorString(he));
+        fsea_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return FSEA_OK;
+}
+
+int fsea_plan_create(fsea_plan **out, int fft_size, int hop, int mode, int device) {
+    return fsea_plan_create_variant(out, fft_size, hop, mode, device, "");
+}
+
+int fsea_plan_destroy(fsea_plan *p) {
+    if (!p) return FSEA_OK;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_in) (void)hipFree(p->d_in);
+    if (p->d_out) (void)hipFree(p->d_out);
+    if (p->d_aux) (void)hipFree(p->d_aux);
+    if (p->d_acc) (void)hipFree(p->d_acc);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return FSEA_OK;
+}
+
+size_t fsea_plan_row_bytes(const fsea_plan *p) { return p ? (size_t)p->n * mode_elem_bytes(p->mode) : 0; }
+int fsea_plan_fft_size(const fsea_plan *p) { return p ? p->n : 0; }
+const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_name.c_str() : ""; }
+
+int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned *block, size_t *lds_bytes) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    if (grid) *grid = grid_for(p, p->mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8, n_frames);
+    if (block) *block = (unsigned)p->entry->wg;
+    if (lds_bytes) *lds_bytes = p->entry->lds_bytes;
+    return FSEA_OK;
+}
+
+int fsea_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, void *d_out, void *stream) {
+    int rc = check_exec_args(p, d_iq, d_out, 16);
+    if (rc) return rc;
+    FSEA_HIP(hipSetDevice(p->device));
+    return launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, d_out,
+                  stream ? static_cast<hipStream_t>(stream) : p->stream);
+}
+
+int fsea_exec_u8_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip, void *out) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    if (n_frames == 0) return FSEA_OK;
+    if (!iq || !out) return fail(FSEA_EINVAL, "NULL buffer");
+    std::lock_guard<std::mutex> lock(p->mu);
+    FSEA_HIP(hipSetDevice(p->device));
+    const size_t in_bytes = 2 * ((n_frames - 1) * (size_t)p->hop + (size_t)p->n);
+    const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
+    int rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes);
+    if (rc) return rc;
+    rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
+    if (rc) return rc;
+    FSEA_HIP(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
+    rc = launch(p, fsea::IN_U8, p->d_in, n_frames, flip, p->mode, p->d_out, p->stream);
+    if (rc) return rc;
+    FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    FSEA_HIP(hipStreamSynchronize(p->stream));
+    return FSEA_OK;
+}
+
+int fsea_exec_f64_host(fsea_plan *p, const double *iq, size_t n_frames, void *out) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    if (n_frames == 0) return FSEA_OK;
+    if (!iq || !out) return fail(FSEA_EINVAL, "NULL buffer");
+    std::lock_guard<std::mutex> lock(p->mu);
+    FSEA_HIP(hipSetDevice(p->device));
+    const size_t n_samples = (n_frames - 1) * (size_t)p->hop + (size_t)p->n;
+    const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
+    int rc = ensure(&p->d_aux, &p->d_aux_bytes, n_samples * 2 * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(&p->d_in, &p->d_in_bytes, n_samples * 2 * sizeof(float));
+    if (rc) return rc;
+    rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
+    if (rc) return rc;
+    FSEA_HIP(hipMemcpyAsync(p->d_aux, iq, n_samples * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    const size_t n_vals = n_samples * 2;
+    unsigned blocks = (unsigned)((n_vals + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fsea_f64_to_f32_kernel, dim3(blocks), dim3(256), 0, p->stream,
+                       static_cast<const double *>(p->d_aux), static_cast<float *>(p->d_in), n_vals);
+    rc = launch(p, fsea::IN_F32, p->d_in, n_frames, 0, p->mode, p->d_out, p->stream);
+    if (rc) return rc;
+    FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    FSEA_HIP(hipStreamSynchronize(p->stream));
+    return FSEA_OK;
+}
+
+int fsea_mean_magnitude_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, double *mean,
+                                  void *stream) {
+    if (!p || !mean) return fail(FSEA_EINVAL, "NULL argument");
+    if (!d_iq) return fail(FSEA_EINVAL, "NULL buffer");
+    if (n_frames == 0) {
+        *mean = 0.0;
+        return FSEA_OK;
+    }
+    std::lock_guard<std::mutex> lock(p->mu);
+    FSEA_HIP(hipSetDevice(p->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    const size_t count = n_frames * (size_t)p->n;
+    int rc = ensure(&p->d_aux, &p->d_aux_bytes, count * sizeof(float));
+    if (rc) return rc;
+    rc = launch(p, fsea::IN_U8, d_iq, n_frames, flip, FSEA_MODE_MAG_NODC_F32, p->d_aux, s);
+    if (rc) return rc;
+    FSEA_HIP(hipMemsetAsync(p->d_acc, 0, sizeof(double), s));
+    unsigned blocks = (unsigned)((count + 1023) / 1024);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(fsea_sum_f32_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(p->d_aux), count,
+                       p->d_acc);
+    double total = 0.0;
+    FSEA_HIP(hipMemcpyAsync(&total, p->d_acc, sizeof(double), hipMemcpyDeviceToHost, s));
+    FSEA_HIP(hipStreamSynchronize(s));
+    *mean = total / (double)count;
+    return FSEA_OK;
+}
+
+int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x, uint32_t dst_y, uint32_t width,
+                              uint32_t height, uint32_t dst_stride, uint32_t src_stride, int device, void *stream) {
+    if (!d_dst || !d_src) return fail(FSEA_EINVAL, "NULL buffer");
+    if (width == 0 || height == 0) return FSEA_OK;
+    if (dst_x + width > dst_stride || width > src_stride) return fail(FSEA_EINVAL, "tile does not fit the row stride");
+    FSEA_HIP(hipSetDevice(device));
+    const unsigned bx = 64;
+    dim3 grid((width / 4 + bx) / bx, height < 4096 ? height : 4096);
+    hipLaunchKernelGGL(fsea_composite_max_kernel, grid, dim3(bx), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint8_t *>(d_dst), static_cast<const uint8_t *>(d_src), dst_x, dst_y, width, height,
+                       dst_stride, src_stride);
+    FSEA_HIP(hipGetLastError());
+    return FSEA_OK;
+}
+
+int fsea_device_alloc(int device, size_t bytes, void **d_ptr) {
+    if (!d_ptr) return fail(FSEA_EINVAL, "NULL out-pointer");
+    FSEA_HIP(hipSetDevice(device));
+    FSEA_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return FSEA_OK;
+}
+
+int fsea_device_free(int device, void *d_ptr) {
+    if (!d_ptr) return FSEA_OK;
+    FSEA_HIP(hipSetDevice(device));
+    FSEA_HIP(hipFree(d_ptr));
+    return FSEA_OK;
+}
+
+int fsea_copy_to_device(int device, void *d_dst, const void *src, size_t bytes) {
+    FSEA_HIP(hipSetDevice(device));
+    FSEA_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return FSEA_OK;
+}
+
+int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes) {
+    FSEA_HIP(hipSetDevice(device));
+    FSEA_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return FSEA_OK;
+}
+
+int fsea_stream_synchronize(fsea_plan *p, void *stream) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_HIP(hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : p->stream));
+    return FSEA_OK;
+}
+
+int fsea_time_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, void *d_out, void *stream,
+                             int reps, float *avg_ms) {
+    int rc = check_exec_args(p, d_iq, d_out, 16);
+    if (rc) return rc;
+    if (reps <= 0 || !avg_ms) return fail(FSEA_EINVAL, "reps must be > 0 and avg_ms non-NULL");
+    FSEA_HIP(hipSetDevice(p->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    FSEA_HIP(hipEventRecord(p->ev0, s));
+    for (int i = 0; i < reps; ++i) {
+        rc = launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, d_out, s);
+        if (rc) return rc;
+    }
+    FSEA_HIP(hipEventRecord(p->ev1, s));
+    FSEA_HIP(hipEventSynchronize(p->ev1));
+    float ms = 0.f;
+    FSEA_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    *avg_ms = ms / (float)reps;
+    return FSEA_OK;
+}
+
+}  // extern "C"

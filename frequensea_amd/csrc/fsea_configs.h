@@ -1,0 +1,15 @@
+// fsea_configs.h -- the kernel configurations that are compiled into
+// libfsea_hip.so (and, for index-math tests on the CPU, into tests/emu).
+// FftCfg arguments: N, T, FPW, WPE, NP, R0, R1, R2, R3, TWL, TWR.
+#pragma once
+
+// single-wave frames, no s_barrier
+#define FSEA_CFG_128 128, 8, 32, 2, 2, 16, 8, 1, 1, true, true
+#define FSEA_CFG_256 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true
+#define FSEA_CFG_512 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true
+#define FSEA_CFG_1024 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true
+#define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true
+// multi-wave frames
+#define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true
+#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
+#define FSEA_CFG_16384 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true

@@ -1,0 +1,613 @@
+// fsea_fft_core.h -- device-side building blocks of the gfx950 IQ-FFT kernels.
+//
+// One workgroup owns FPW frames at a time; a frame is spread over T threads
+// with P = N/T points held in registers per thread.  The transform is a
+// Stockham autosort FFT in NP passes of radix R[i]: pass 0 reads the 8-bit IQ
+// straight from HBM (coalesced, converted in registers, (-1)^n folded into the
+// butterflies by operand negation), every pass does an in-register radix-R[i]
+// DFT, and passes exchange through one padded LDS buffer.  The last pass fuses
+// the magnitude / dB epilogue and writes the output row.
+//
+// What it replaces in the reference (paths under /root/reference):
+//   src/nrf.c:100-109 (byte flip), 599-614 (unpack + (-1)^n), 615 (FFTW),
+//   619-630 (magnitude + DC patch); c/fft-batch.c:62-69,83-94;
+//   c/fft-batch-broad.c:64-71,106-121.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace fsea {
+
+// ---------------------------------------------------------------------------
+// compile-time helpers
+// ---------------------------------------------------------------------------
+constexpr int ilog2c(int n) {
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l;
+}
+
+constexpr int bitrev_c(int i, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) {
+        if (i & (1 << b)) r |= 1 << (bits - 1 - b);
+    }
+    return r;
+}
+
+// LDS index padding (complex units): 2 complexes (16 B) after every P (the
+// points one thread holds).  Pass 0 writes one contiguous run of P complexes
+// per lane; with the pad consecutive lanes start 16 B further round the banks,
+// so the ds_write_b128 of a lane group are conflict-free, and even indices
+// stay 16-byte aligned for the vector reads of the later passes.
+template <int P>
+__host__ __device__ constexpr int lds_pad(int idx) {
+    return idx + ((idx / P) << 1);
+}
+
+// cos(2 pi m / 64) for the in-register DFT constants.
+__host__ __device__ constexpr float cos64q(int i) {
+    constexpr float t[17] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f,
+                             9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f,
+                             8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f,
+                             6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f,
+                             3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f,
+                             9.801714033e-02f, 0.0f};
+    return t[i];
+}
+__host__ __device__ constexpr float cos64(int m) {
+    m &= 63;
+    if (m <= 16) return cos64q(m);
+    if (m <= 32) return -cos64q(32 - m);
+    if (m <= 48) return -cos64q(m - 32);
+    return cos64q(64 - m);
+}
+__host__ __device__ constexpr float sin64(int m) { return cos64((m - 16) & 63); }
+
+// ---------------------------------------------------------------------------
+// radix-2 butterfly with the constant twiddle w = exp(-2 pi i k / L).
+// (a, b) <- (a + w b, a - w b).  L and k are compile-time after unrolling.
+// The general case uses the FMA form: plus = a + w b (4 fma), minus = 2a - plus
+// (2 fma) -- 6 VALU instead of 8.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bfly_const(int L, int k, float2 &a, float2 &b) {
+    if (k == 0) {
+        const float2 t = b;
+        b = make_float2(a.x - t.x, a.y - t.y);
+        a = make_float2(a.x + t.x, a.y + t.y);
+    } else if (4 * k == L) {  // w = -i : w b = (b.y, -b.x)
+        const float2 t = make_float2(b.y, -b.x);
+        b = make_float2(a.x - t.x, a.y - t.y);
+        a = make_float2(a.x + t.x, a.y + t.y);
+    } else if (8 * k == L) {  // w = (1 - i)/sqrt2 : w b = h (b.x + b.y, b.y - b.x)
+        const float h = 0.70710678118654752f;
+        const float s = b.x + b.y, d = b.y - b.x;
+        b = make_float2(__builtin_fmaf(-h, s, a.x), __builtin_fmaf(-h, d, a.y));
+        a = make_float2(__builtin_fmaf(h, s, a.x), __builtin_fmaf(h, d, a.y));
+    } else if (8 * k == 3 * L) {  // w = (-1 - i)/sqrt2 : w b = h (b.y - b.x, -(b.x + b.y))
+        const float h = 0.70710678118654752f;
+        const float s = b.y - b.x, d = b.x + b.y;
+        b = make_float2(__builtin_fmaf(-h, s, a.x), __builtin_fmaf(h, d, a.y));
+        a = make_float2(__builtin_fmaf(h, s, a.x), __builtin_fmaf(-h, d, a.y));
+    } else {
+        const int m = k * (64 / L);
+        const float wr = cos64(m), wi = -sin64(m);
+        float pr = __builtin_fmaf(wr, b.x, a.x);
+        pr = __builtin_fmaf(-wi, b.y, pr);
+        float pi = __builtin_fmaf(wr, b.y, a.y);
+        pi = __builtin_fmaf(wi, b.x, pi);
+        b = make_float2(__builtin_fmaf(2.0f, a.x, -pr), __builtin_fmaf(2.0f, a.y, -pi));
+        a = make_float2(pr, pi);
+    }
+}
+
+// R-point DFT (forward, -1 exponent) over x[0], x[S], ..., x[(R-1)S];
+// natural order in and out.  Bit reversal is register renaming only.
+template <int R, int S>
+__device__ __forceinline__ void dft_regs(float2 *x) {
+    static_assert(R >= 2 && R <= 64 && (R & (R - 1)) == 0, "radix must be 2..64");
+    constexpr int BITS = ilog2c(R);
+    float2 y[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) y[bitrev_c(i, BITS)] = x[i * S];
+#pragma unroll
+    for (int half = 1; half < R; half <<= 1) {
+#pragma unroll
+        for (int base = 0; base < R; base += 2 * half) {
+#pragma unroll
+            for (int k = 0; k < half; ++k) {
+                bfly_const(2 * half, k, y[base + k], y[base + k + half]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) x[i * S] = y[i];
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+    return make_float2(__builtin_fmaf(-a.y, w.y, a.x * w.x), __builtin_fmaf(a.y, w.x, a.x * w.y));
+}
+
+// ---------------------------------------------------------------------------
+// configuration
+// ---------------------------------------------------------------------------
+enum : int {
+    MODE_MAG = 0,
+    MODE_DB10_U8 = 1,
+    MODE_DB5_U8_DCFIX = 2,
+    MODE_COMPLEX = 3,
+    MODE_MAG_NODC = 4,
+    MODE_DB_F32 = 5
+};
+enum : int { IN_U8 = 0, IN_F32 = 1 };
+
+// N: transform size; T: threads per frame; FPW: frames per workgroup;
+// NP passes of radix R0..R3 (unused = 1).  TWL: middle-pass twiddle tables
+// live in LDS (else they are fetched from the global table every frame);
+// TWR: the last pass keeps its twiddles in registers across the frame loop.
+template <int N_, int T_, int FPW_, int WPE_, int NP_, int R0_, int R1_, int R2_ = 1, int R3_ = 1,
+          bool TWL_ = true, bool TWR_ = true>
+struct FftCfg {
+    static constexpr int N = N_, T = T_, FPW = FPW_, NP = NP_;
+    static constexpr int WPE = WPE_;  // waves per SIMD the register budget must allow
+    static constexpr int P = N_ / T_;
+    static constexpr int WG = T_ * FPW_;
+    static constexpr bool TWL = TWL_, TWR = TWR_;
+    static constexpr int R(int i) { return i == 0 ? R0_ : i == 1 ? R1_ : i == 2 ? R2_ : R3_; }
+    static constexpr int C(int i) { return P / R(i); }
+    static constexpr int Ns(int i) { return i == 0 ? 1 : Ns(i - 1) * R(i - 1); }
+    static constexpr int tw_len(int i) { return i == 0 ? 0 : (R(i) - 1) * Ns(i); }
+    // LDS (in float2 units): FPW padded frames, then the middle-pass tables.
+    static constexpr int pad(int idx) { return lds_pad<N_ / T_>(idx); }
+    static constexpr int LDS_FRAME = N_ + 2 * T_;
+    static constexpr int lds_tw_off(int i) {
+        return i <= 1 ? FPW_ * LDS_FRAME : lds_tw_off(i - 1) + tw_len(i - 1);
+    }
+    static constexpr int LDS_TOTAL = TWL_ ? lds_tw_off(NP_ - 1) : FPW_ * LDS_FRAME;
+    static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
+    static_assert(N_ % T_ == 0, "T must divide N");
+    static_assert(NP_ >= 2 && NP_ <= 4, "2..4 passes");
+};
+
+struct FftArgs {
+    const void *in;       // u8 interleaved IQ, or f32 interleaved complex
+    void *out;            // n_frames rows
+    size_t n_frames;
+    size_t hop;           // samples between frame starts
+    uint32_t xormask;     // u8 input: 0 when flip (raw int8), 0x80808080 otherwise
+    int mode;             // MODE_*
+    const float2 *tw[4];  // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
+};
+
+// ---------------------------------------------------------------------------
+// small typed memory helpers
+// ---------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void ld_c(const float2 *p, float2 *dst) {
+    if constexpr (C == 1) {
+        dst[0] = *p;
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+            const float4 q = *reinterpret_cast<const float4 *>(p + c);
+            dst[c] = make_float2(q.x, q.y);
+            dst[c + 1] = make_float2(q.z, q.w);
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void st_c(float2 *p, const float2 *src) {
+    if constexpr (C == 1) {
+        *p = src[0];
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+            *reinterpret_cast<float4 *>(p + c) = make_float4(src[c].x, src[c].y, src[c + 1].x, src[c + 1].y);
+        }
+    }
+}
+
+// C consecutive output elements of type E (float, uint8_t or float2) at p.
+template <int C>
+__device__ __forceinline__ void st_out(float *p, const float *v) {
+    if constexpr (C == 1) {
+        p[0] = v[0];
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            *reinterpret_cast<float4 *>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void st_out(uint8_t *p, const uint8_t *v) {
+    if constexpr (C == 1) {
+        p[0] = v[0];
+    } else if constexpr (C == 2) {
+        *reinterpret_cast<uint16_t *>(p) = (uint16_t)(v[0] | (v[1] << 8));
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            *reinterpret_cast<uint32_t *>(p + c) =
+                (uint32_t)v[c] | ((uint32_t)v[c + 1] << 8) | ((uint32_t)v[c + 2] << 16) | ((uint32_t)v[c + 3] << 24);
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void st_out(float2 *p, const float2 *v) {
+    st_c<C>(p, v);
+}
+
+// Raw input words of pass 0: C samples per row.
+template <int IN, int C>
+struct RawRow;
+template <>
+struct RawRow<IN_U8, 1> { uint16_t w; };
+template <>
+struct RawRow<IN_U8, 2> { uint32_t w; };
+template <>
+struct RawRow<IN_U8, 4> { uint2 w; };
+template <>
+struct RawRow<IN_U8, 8> { uint4 w; };
+template <int C>
+struct RawRow<IN_F32, C> { float2 w[C]; };
+
+__device__ __forceinline__ float s8f(uint32_t w, int byte) {
+    return (float)(int8_t)(uint8_t)(w >> (8 * byte));
+}
+
+// Convert one raw row to C complex samples in integer units (u - 128); the
+// 1/256 scale is applied by the epilogue.  (-1)^n is applied here as a sign
+// on odd columns (row strides are even), which the compiler folds into the
+// first butterflies as operand negation.
+template <int IN, int C>
+__device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t xormask, int j0, float2 *dst) {
+    if constexpr (IN == IN_F32) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float sg = ((j0 + c) & 1) ? -1.0f : 1.0f;
+            dst[c] = make_float2(sg * raw.w[c].x, sg * raw.w[c].y);
+        }
+    } else if constexpr (C == 1) {
+        const uint32_t w = (uint32_t)raw.w ^ xormask;
+        const float sg = (j0 & 1) ? -1.0f : 1.0f;
+        dst[0] = make_float2(sg * s8f(w, 0), sg * s8f(w, 1));
+    } else {
+        uint32_t words[C / 2];
+        if constexpr (C == 2) {
+            words[0] = raw.w;
+        } else if constexpr (C == 4) {
+            words[0] = raw.w.x;
+            words[1] = raw.w.y;
+        } else {
+            words[0] = raw.w.x;
+            words[1] = raw.w.y;
+            words[2] = raw.w.z;
+            words[3] = raw.w.w;
+        }
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) {
+            const uint32_t w = words[q] ^ xormask;
+            dst[2 * q] = make_float2(s8f(w, 0), s8f(w, 1));        // even column: +
+            dst[2 * q + 1] = make_float2(-s8f(w, 2), -s8f(w, 3));  // odd column: -
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the kernel body
+// ---------------------------------------------------------------------------
+// MODE_T >= 0 fixes the epilogue at compile time (the hot MAG path); MODE_T = -1
+// dispatches on args.mode at run time (uniform branch).
+template <class Cfg, int IN, int MODE_T = -1>
+struct FftKernel {
+    static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
+    static constexpr int LAST = NP - 1;
+    static constexpr int R0 = Cfg::R(0), C0 = Cfg::C(0);
+    static constexpr int RL = Cfg::R(LAST), CL = Cfg::C(LAST), NsL = Cfg::Ns(LAST);
+    static constexpr bool ONE_WAVE = (Cfg::WG <= 64) || (T <= 64 && (64 % T) == 0);
+    using Raw = RawRow<IN, C0>;
+
+    // Frames of one workgroup exchange through LDS.  When a frame lives inside
+    // a single wavefront no s_barrier is needed: LDS operations of one wave
+    // execute in order.
+    static __device__ __forceinline__ void frame_sync() {
+        if constexpr (ONE_WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    }
+
+    static __device__ __forceinline__ void load_raw(const FftArgs &a, size_t frame, int t, Raw *raw) {
+        constexpr int STRIDE = N / R0;
+        if constexpr (IN == IN_U8) {
+            const uint8_t *base = static_cast<const uint8_t *>(a.in) + 2 * (frame * a.hop + (size_t)(C0 * t));
+#pragma unroll
+            for (int r = 0; r < R0; ++r) {
+                const uint8_t *p = base + 2 * (size_t)(r * STRIDE);
+                if constexpr (C0 == 1) raw[r].w = *reinterpret_cast<const uint16_t *>(p);
+                if constexpr (C0 == 2) raw[r].w = *reinterpret_cast<const uint32_t *>(p);
+                if constexpr (C0 == 4) raw[r].w = *reinterpret_cast<const uint2 *>(p);
+                if constexpr (C0 == 8) raw[r].w = *reinterpret_cast<const uint4 *>(p);
+            }
+        } else {
+            const float2 *base = static_cast<const float2 *>(a.in) + frame * a.hop + (size_t)(C0 * t);
+#pragma unroll
+            for (int r = 0; r < R0; ++r) ld_c<C0>(base + r * STRIDE, raw[r].w);
+        }
+    }
+
+    // twiddle multiply for pass I (I >= 1): v[r*C + c] *= W^{r k}, k = (C t + c) % Ns
+    template <int I>
+    static __device__ __forceinline__ void apply_twiddles(float2 *v, const float2 *tw, int t) {
+        constexpr int R = Cfg::R(I), C = Cfg::C(I), Ns = Cfg::Ns(I);
+        const int k0 = (C * t) % Ns;
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            float2 w[C];
+            if constexpr (Ns % C == 0) {
+                ld_c<C>(tw + (r - 1) * Ns + k0, w);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) w[c] = tw[(r - 1) * Ns + (C * t + c) % Ns];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) v[r * C + c] = cmul(v[r * C + c], w[c]);
+        }
+    }
+
+    // LDS addressing.  pad(idx) = idx + 2*(idx / P) is not affine in idx, but every
+    // access pattern here is "thread base + r * constant" once the division is taken
+    // on the thread part only; written out so that the r-dependent part becomes the
+    // immediate offset of the ds_* instruction.
+    template <int I>
+    static __device__ __forceinline__ void lds_write(float2 *lds, const float2 *v, int t) {
+        constexpr int R = Cfg::R(I), C = Cfg::C(I), Ns = Cfg::Ns(I);
+        if constexpr (Ns == 1 && (R % 2) == 0) {
+            // column c owns R contiguous outputs at (C t + c) R: the thread's P
+            // outputs are the run [P t, P t + P), i.e. pad adds exactly 2 t.
+            float2 *base = lds + (unsigned)((P + 2) * t);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+#pragma unroll
+                for (int r = 0; r < R; r += 2) {
+                    const float2 pr[2] = {v[r * C + c], v[(r + 1) * C + c]};
+                    st_c<2>(base + (c * R + r), pr);
+                }
+            }
+        } else if constexpr (Ns % C == 0) {
+            const unsigned j = (unsigned)(C * t);
+            const unsigned j0 = (j / Ns) * (Ns * R) + (j % Ns);
+            if constexpr (Ns % P == 0) {
+                float2 *base = lds + Cfg::pad(j0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) st_c<C>(base + r * (Ns + 2 * (Ns / P)), v + r * C);
+            } else {
+                // Ns < P: rows r = q r' + b share the base of their residue b
+                constexpr int Q = P / Ns;
+                static_assert(P % Ns == 0 && R % Q == 0, "pad addressing needs Ns | P and (P/Ns) | R");
+#pragma unroll
+                for (int b = 0; b < Q; ++b) {
+                    float2 *base = lds + Cfg::pad(j0 + b * Ns);
+#pragma unroll
+                    for (int rq = 0; rq < R / Q; ++rq) st_c<C>(base + rq * (P + 2), v + (rq * Q + b) * C);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int j = C * t + c;
+                const int j0 = (j / Ns) * (Ns * R) + (j % Ns);
+#pragma unroll
+                for (int r = 0; r < R; ++r) lds[Cfg::pad(j0 + r * Ns)] = v[r * C + c];
+            }
+        }
+    }
+
+    template <int I>
+    static __device__ __forceinline__ void lds_read(const float2 *lds, float2 *v, int t) {
+        constexpr int R = Cfg::R(I), C = Cfg::C(I);
+        constexpr int STRIDE = N / R;
+        if constexpr (STRIDE % P == 0) {
+            const float2 *base = lds + Cfg::pad(C * t);
+#pragma unroll
+            for (int r = 0; r < R; ++r) ld_c<C>(base + r * (STRIDE + 2 * (STRIDE / P)), v + r * C);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) ld_c<C>(lds + Cfg::pad(C * t + r * STRIDE), v + r * C);
+        }
+    }
+
+    // middle pass I (1 <= I < LAST): read, twiddle, DFT, write back
+    template <int I>
+    static __device__ __forceinline__ void middle_pass(float2 *lds, const float2 *lds_all, float2 *v,
+                                                       const FftArgs &a, int t) {
+        if constexpr (I < LAST) {
+            constexpr int R = Cfg::R(I), C = Cfg::C(I);
+            lds_read<I>(lds, v, t);
+            frame_sync();  // everyone has read before anyone overwrites
+            const float2 *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
+            apply_twiddles<I>(v, tw, t);
+#pragma unroll
+            for (int c = 0; c < C; ++c) dft_regs<R, C>(v + c);
+            lds_write<I>(lds, v, t);
+            frame_sync();
+            middle_pass<I + 1>(lds, lds_all, v, a, t);
+        }
+    }
+
+    // fused epilogue for the row held as v[r*CL + c] = bin CL t + c + r NsL
+    static __device__ __forceinline__ void epilogue(const FftArgs &a, size_t frame, float2 *v, int t) {
+        constexpr float SC = (IN == IN_U8) ? (1.0f / 256.0f) : 1.0f;  // input scale u8/256
+        constexpr float SC2 = SC * SC;
+        const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
+        const bool patched = (mode == MODE_MAG) || (mode == MODE_DB5_U8_DCFIX);
+        // Offset-binary input carries a DC term 0.5 per component, which the
+        // (-1)^n centring moves to bin N/2 exactly: 0.5 N (1 + i).  The kernel
+        // transforms (u - 128) instead and restores that bin analytically in
+        // the modes that keep it (in integer units: 128 N).
+        if (IN == IN_U8 && !patched && t == 0) {
+            v[(RL / 2) * CL].x += 128.0f * (float)N;
+            v[(RL / 2) * CL].y += 128.0f * (float)N;
+        }
+        const size_t row = frame * (size_t)N;
+        const int k0 = CL * t;
+        if (mode == MODE_COMPLEX) {
+            float2 *o = static_cast<float2 *>(a.out) + row + k0;
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                float2 z[CL];
+#pragma unroll
+                for (int c = 0; c < CL; ++c) z[c] = make_float2(v[r * CL + c].x * SC, v[r * CL + c].y * SC);
+                st_out<CL>(o + r * NsL, z);
+            }
+        } else if (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) {
+            // 10*log10(p + 1e-20) * s = (10 s log10(2)) * log2(p + 1e-20)
+            const float kdb = (mode == MODE_DB10_U8 ? 100.0f : 50.0f) * 0.30102999566398120f;
+            uint8_t *o = static_cast<uint8_t *>(a.out) + row + k0;
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                uint8_t px[CL];
+#pragma unroll
+                for (int c = 0; c < CL; ++c) {
+                    const float2 z = v[r * CL + c];
+                    const float p = __builtin_fmaf(z.x, z.x, z.y * z.y) * SC2;
+                    const float d = kdb * __builtin_amdgcn_logf(p + 1.0e-20f);
+                    int q = (int)d;  // truncation toward zero, as the C cast in the reference
+                    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                    px[c] = (uint8_t)q;
+                }
+                if (patched && r == RL / 2 && t == 0) {
+#pragma unroll
+                    for (int c = 1; c < CL; ++c) o[r * NsL + c] = px[c];
+                } else {
+                    st_out<CL>(o + r * NsL, px);
+                }
+                if (patched && r == RL / 2 - 1 && t == T - 1) o[r * NsL + CL] = px[CL - 1];
+            }
+        } else {
+            float *o = static_cast<float *>(a.out) + row + k0;
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                float m[CL];
+#pragma unroll
+                for (int c = 0; c < CL; ++c) {
+                    const float2 z = v[r * CL + c];
+                    const float p = __builtin_fmaf(z.x, z.x, z.y * z.y) * SC2;
+                    if (mode == MODE_DB_F32) {
+                        m[c] = (10.0f * 0.30102999566398120f) * __builtin_amdgcn_logf(p + 1.0e-20f);
+                    } else {
+                        m[c] = __builtin_amdgcn_sqrtf(p);
+                    }
+                }
+                if (patched && r == RL / 2 && t == 0) {
+#pragma unroll
+                    for (int c = 1; c < CL; ++c) o[r * NsL + c] = m[c];
+                } else {
+                    st_out<CL>(o + r * NsL, m);
+                }
+                if (patched && r == RL / 2 - 1 && t == T - 1) o[r * NsL + CL] = m[CL - 1];
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void run(const FftArgs &a, float2 *lds_all) {
+        const int tid = threadIdx.x;
+        const int slot = tid / T;
+        const int t = tid % T;
+        float2 *lds = lds_all + slot * Cfg::LDS_FRAME;
+
+        // middle-pass twiddle tables -> LDS, once per workgroup
+        if constexpr (Cfg::TWL && NP > 2) {
+            constexpr int TOT = Cfg::LDS_TOTAL - FPW * Cfg::LDS_FRAME;
+            float2 *dst = lds_all + FPW * Cfg::LDS_FRAME;
+            for (int i = tid; i < TOT; i += Cfg::WG) {
+                // tables of passes 1..LAST-1 are contiguous in the global image too
+                dst[i] = a.tw[1][i];
+            }
+            __syncthreads();
+        }
+
+        // last-pass twiddles in registers for the lifetime of the workgroup
+        float2 twl[Cfg::TWR ? (RL - 1) * CL : 1];
+        if constexpr (Cfg::TWR) {
+#pragma unroll
+            for (int r = 1; r < RL; ++r) ld_c<CL>(a.tw[LAST] + (r - 1) * NsL + CL * t, twl + (r - 1) * CL);
+        }
+
+        // XCD-aware unit mapping: workgroup b runs on XCD b % 8; give each XCD a
+        // contiguous range of frames so that overlapped (hop < N) frames share L2.
+        const size_t units = (a.n_frames + FPW - 1) / FPW;
+        const unsigned G = gridDim.x, b = blockIdx.x;
+        size_t u, u_end, u_step;
+        if (G >= 8 && (G & 7) == 0) {
+            const unsigned x = b & 7;
+            u = units * x / 8 + (b >> 3);
+            u_end = units * (x + 1) / 8;
+            u_step = G >> 3;
+        } else {
+            u = b;
+            u_end = units;
+            u_step = G;
+        }
+
+        Raw raw[R0];
+        size_t frame = u * FPW + slot;
+        bool live = (u < u_end) && (frame < a.n_frames);
+        if (live) load_raw(a, frame, t, raw);
+
+        for (; u < u_end; u += u_step) {
+            const size_t un = u + u_step;
+            const size_t frame_n = un * FPW + slot;
+            const bool live_n = (un < u_end) && (frame_n < a.n_frames);
+
+            float2 v[P];
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < P; ++i) v[i] = make_float2(0.f, 0.f);
+            }
+            // prefetch: the next frame's bytes are requested as soon as this frame's
+            // are converted and stay in flight during the whole transform
+            if (live_n) load_raw(a, frame_n, t, raw);
+#pragma unroll
+            for (int c = 0; c < C0; ++c) dft_regs<R0, C0>(v + c);
+            lds_write<0>(lds, v, t);
+            frame_sync();
+            middle_pass<1>(lds, lds_all, v, a, t);
+
+            // last pass
+            lds_read<LAST>(lds, v, t);
+            frame_sync();  // the buffer is free for the next frame's pass 0
+            if constexpr (Cfg::TWR) {
+#pragma unroll
+                for (int r = 1; r < RL; ++r) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) v[r * CL + c] = cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
+                }
+            } else {
+                apply_twiddles<LAST>(v, a.tw[LAST], t);
+            }
+#pragma unroll
+            for (int c = 0; c < CL; ++c) dft_regs<RL, CL>(v + c);
+            if (live) epilogue(a, frame, v, t);
+
+            frame = frame_n;
+            live = live_n;
+        }
+    }
+};
+
+}  // namespace fsea

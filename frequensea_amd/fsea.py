@@ -1,0 +1,185 @@
+"""ctypes binding of libfsea_hip.so (include/fsea.h).  No compute happens here."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+MODE_MAG_F32 = 0
+MODE_DB10_U8 = 1
+MODE_DB5_U8_DCFIX = 2
+MODE_COMPLEX_F32 = 3
+MODE_MAG_NODC_F32 = 4
+MODE_DB_F32 = 5
+
+_MODE_DTYPE = {
+    MODE_MAG_F32: np.float32, MODE_DB10_U8: np.uint8, MODE_DB5_U8_DCFIX: np.uint8,
+    MODE_COMPLEX_F32: np.complex64, MODE_MAG_NODC_F32: np.float32, MODE_DB_F32: np.float32,
+}
+
+# Every symbol include/fsea.h declares; tests check the built library exports all of them.
+EXPORTS = [
+    "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_create_variant",
+    "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device",
+    "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_mean_magnitude_u8_device",
+    "fsea_composite_max_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
+    "fsea_copy_to_host", "fsea_stream_synchronize", "fsea_time_exec_u8_device",
+    "fsea_plan_kernel_name", "fsea_last_error_string",
+]
+
+
+class FseaError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfsea_hip.so")
+
+
+def build(jobs=8):
+    """Compile libfsea_hip.so and libfsea_nrf.so in-tree (hipcc cross-compiles gfx950)."""
+    subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", os.path.join(_HERE, "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host")])
+
+
+_LIB = None
+
+
+def hip_lib():
+    """Load libfsea_hip.so; raises loudly if it was not built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise FseaError("libfsea_hip.so is missing: run frequensea_amd.build() / __graft_entry__.build()")
+        L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.fsea_last_error_string.restype = ctypes.c_char_p
+        L.fsea_device_count.argtypes = [ctypes.POINTER(ci)]
+        L.fsea_plan_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci]
+        L.fsea_plan_create_variant.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.c_char_p]
+        L.fsea_plan_destroy.argtypes = [vp]
+        L.fsea_plan_grid.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
+                                     ctypes.POINTER(sz)]
+        L.fsea_plan_row_bytes.argtypes = [vp]
+        L.fsea_plan_row_bytes.restype = sz
+        L.fsea_plan_fft_size.argtypes = [vp]
+        L.fsea_plan_kernel_name.argtypes = [vp]
+        L.fsea_plan_kernel_name.restype = ctypes.c_char_p
+        L.fsea_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp]
+        L.fsea_exec_u8_host.argtypes = [vp, vp, sz, ci, vp]
+        L.fsea_exec_f64_host.argtypes = [vp, vp, sz, vp]
+        L.fsea_mean_magnitude_u8_device.argtypes = [vp, vp, sz, ci, ctypes.POINTER(ctypes.c_double), vp]
+        L.fsea_composite_max_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 6 + [ci, vp]
+        L.fsea_device_alloc.argtypes = [ci, sz, ctypes.POINTER(vp)]
+        L.fsea_device_free.argtypes = [ci, vp]
+        L.fsea_copy_to_device.argtypes = [ci, vp, vp, sz]
+        L.fsea_copy_to_host.argtypes = [ci, vp, vp, sz]
+        L.fsea_stream_synchronize.argtypes = [vp, vp]
+        L.fsea_time_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp, ci, ctypes.POINTER(ctypes.c_float)]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise FseaError("fsea error %d: %s" % (rc, hip_lib().fsea_last_error_string().decode()))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    hip_lib().fsea_device_count(ctypes.byref(n))
+    return n.value
+
+
+class Plan:
+    """One (fft_size, hop, mode) plan on one device; thin wrapper over fsea_plan_*."""
+
+    def __init__(self, fft_size, hop=None, mode=MODE_MAG_F32, device=0, variant=None):
+        self._L = hip_lib()
+        self._p = ctypes.c_void_p()
+        self.fft_size = fft_size
+        self.hop = fft_size if hop is None else hop
+        self.mode = mode
+        self.device = device
+        if variant is None:
+            _check(self._L.fsea_plan_create(ctypes.byref(self._p), fft_size, self.hop, mode, device))
+        else:
+            _check(self._L.fsea_plan_create_variant(ctypes.byref(self._p), fft_size, self.hop, mode, device,
+                                                    variant.encode()))
+
+    def close(self):
+        if self._p:
+            self._L.fsea_plan_destroy(self._p)
+            self._p = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def row_bytes(self):
+        return self._L.fsea_plan_row_bytes(self._p)
+
+    @property
+    def out_dtype(self):
+        return _MODE_DTYPE[self.mode]
+
+    @property
+    def kernel_name(self):
+        return self._L.fsea_plan_kernel_name(self._p).decode()
+
+    def grid(self, n_frames):
+        g, b, l = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_size_t(0)
+        _check(self._L.fsea_plan_grid(self._p, n_frames, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)))
+        return g.value, b.value, l.value
+
+    def in_bytes(self, n_frames):
+        return 2 * ((n_frames - 1) * self.hop + self.fft_size) if n_frames else 0
+
+    def exec_device(self, d_iq_ptr, n_frames, d_out_ptr, flip=True, stream=0):
+        """Device pointers (ints), asynchronous on `stream` (hipStream_t as int, 0 = plan stream)."""
+        _check(self._L.fsea_exec_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_out_ptr,
+                                           stream or None))
+
+    def time_device(self, d_iq_ptr, n_frames, d_out_ptr, reps, flip=True, stream=0):
+        ms = ctypes.c_float(0)
+        _check(self._L.fsea_time_exec_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_out_ptr,
+                                                stream or None, reps, ctypes.byref(ms)))
+        return ms.value
+
+    def synchronize(self, stream=0):
+        _check(self._L.fsea_stream_synchronize(self._p, stream or None))
+
+    def exec_host(self, iq_u8, n_frames=None, flip=True):
+        iq = np.ascontiguousarray(iq_u8, dtype=np.uint8).ravel()
+        if n_frames is None:
+            n_frames = 0 if iq.size < 2 * self.fft_size else (iq.size // 2 - self.fft_size) // self.hop + 1
+        if iq.size < self.in_bytes(n_frames):
+            raise ValueError("iq too short for %d frames" % n_frames)
+        out = np.empty((n_frames, self.fft_size), dtype=self.out_dtype)
+        _check(self._L.fsea_exec_u8_host(self._p, iq.ctypes.data, n_frames, int(bool(flip)), out.ctypes.data))
+        return out
+
+    def exec_host_f64(self, iq_f64, n_frames):
+        iq = np.ascontiguousarray(iq_f64, dtype=np.float64).ravel()
+        if iq.size < self.in_bytes(n_frames):
+            raise ValueError("iq too short for %d frames" % n_frames)
+        out = np.empty((n_frames, self.fft_size), dtype=self.out_dtype)
+        _check(self._L.fsea_exec_f64_host(self._p, iq.ctypes.data, n_frames, out.ctypes.data))
+        return out
+
+    def mean_magnitude_device(self, d_iq_ptr, n_frames, flip=True, stream=0):
+        m = ctypes.c_double(0)
+        _check(self._L.fsea_mean_magnitude_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)),
+                                                     ctypes.byref(m), stream or None))
+        return m.value
+
+
+def composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride, src_stride, device=0, stream=0):
+    _check(hip_lib().fsea_composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride,
+                                               src_stride, device, stream or None))

@@ -1,0 +1,139 @@
+/*
+ * nrf_fft.c -- frequensea's nrf_fft block with the spectrum computed by
+ * libfsea_hip.so on an MI355X (include/nrf.h, include/fsea.h).
+ *
+ * Reference behaviour restated (paths under /root/reference):
+ *   nrf_fft_new         src/nrf.c:557-567
+ *   nrf_fft_shift       src/nrf.c:569-596
+ *   nrf_fft_process     src/nrf.c:598-631
+ *   nrf_fft_get_buffer  src/nrf.c:633-635
+ *   nrf_fft_free        src/nrf.c:637-642 (which leaks `buffer`; fixed here)
+ * What moved to the GPU: the unpack/centre loop, the FFT and the magnitude +
+ * DC patch (one fused kernel).  What changed on the host: the history is a
+ * ring (the reference memmoves the whole history, 8 MiB at 1024x1024, per
+ * row: src/nrf.c:617), linearised only in nrf_fft_get_buffer.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fsea.h"
+#include "nrf.h"
+
+static void fsea_fatal(const char *what, int rc) {
+    /* same convention as src/nrf.c:54-78: print and exit */
+    fprintf(stderr, "NRF FFT fatal error: %s failed (%d): %s\n", what, rc, fsea_last_error_string());
+    exit(EXIT_FAILURE);
+}
+
+nrf_fft *nrf_fft_new(int fft_size, int fft_history_size) {
+    nrf_fft *fft = (nrf_fft *)calloc(1, sizeof(nrf_fft));
+    if (fft == NULL) {
+        fprintf(stderr, "NRF FFT fatal error: out of memory\n");
+        exit(EXIT_FAILURE);
+    }
+    nrf_block_init(&fft->block, NRF_BLOCK_GENERIC, (nrf_block_process_fn)nrf_fft_process,
+                   (nrf_block_result_fn)nrf_fft_get_buffer);
+    fft->fft_size = fft_size;
+    fft->fft_history_size = fft_history_size;
+    fsea_plan *plan = NULL;
+    int rc = fsea_plan_create(&plan, fft_size, fft_size, FSEA_MODE_MAG_F32, 0);
+    if (rc != FSEA_OK) fsea_fatal("fsea_plan_create", rc);
+    fft->backend = plan;
+    fft->buffer = (double *)calloc((size_t)fft_size * (size_t)fft_history_size, sizeof(double));
+    fft->row_f32 = (float *)calloc((size_t)fft_size, sizeof(float));
+    fft->scratch = calloc((size_t)fft_size * 2, sizeof(double));
+    if (fft->buffer == NULL || fft->row_f32 == NULL || fft->scratch == NULL) {
+        fprintf(stderr, "NRF FFT fatal error: out of memory\n");
+        exit(EXIT_FAILURE);
+    }
+    fft->ring_head = 0;
+    pthread_mutex_init(&fft->mutex, NULL);
+    return fft;
+}
+
+void nrf_fft_shift(nrf_fft *fft, double d) {
+    const int n = fft->fft_size;
+    const int shift = (int)round(n / d);
+    if (shift == 0) return;
+    pthread_mutex_lock(&fft->mutex);
+    if (abs(shift) >= n) {
+        /* shifted out of range: start over */
+        memset(fft->buffer, 0, sizeof(double) * (size_t)n * (size_t)fft->fft_history_size);
+    } else {
+        /* the per-row operation does not depend on the row order, so it is
+         * applied to the ring as stored */
+        for (int y = 0; y < fft->fft_history_size; y++) {
+            double *row = fft->buffer + (size_t)y * (size_t)n;
+            if (shift > 0) {
+                memmove(row, row + shift, sizeof(double) * (size_t)(n - shift));
+                memset(row + (n - shift), 0, sizeof(double) * (size_t)shift);
+            } else {
+                memmove(row - shift, row, sizeof(double) * (size_t)(n + shift));
+                memset(row, 0, sizeof(double) * (size_t)(-shift));
+            }
+        }
+    }
+    pthread_mutex_unlock(&fft->mutex);
+}
+
+void nrf_fft_process(nrf_fft *fft, nut_buffer *buffer) {
+    const int n = fft->fft_size;
+    fsea_plan *plan = (fsea_plan *)fft->backend;
+    /* The reference unpacks every sample of the buffer but transforms only the
+     * first fft_size (src/nrf.c:599-615); a shorter buffer is zero-padded here
+     * (the reference would transform stale samples of an earlier call). */
+    const int have = (buffer->length * buffer->channels) / 2;
+    pthread_mutex_lock(&fft->mutex);
+    int rc;
+    if (buffer->type == NUT_BUFFER_U8) {
+        const uint8_t *iq = buffer->data.u8;
+        if (have < n) {
+            /* missing samples are 0.0, i.e. u8 value 0 under x = u8 / 256.0 */
+            uint8_t *pad = (uint8_t *)fft->scratch;
+            memset(pad, 0, (size_t)n * 2);
+            memcpy(pad, buffer->data.u8, (size_t)have * 2);
+            iq = pad;
+        }
+        /* device buffers are already offset binary (src/nrf.c:103-106) -> flip = 0 */
+        rc = fsea_exec_u8_host(plan, iq, 1, 0, fft->row_f32);
+        if (rc != FSEA_OK) fsea_fatal("fsea_exec_u8_host", rc);
+    } else {
+        const double *iq = buffer->data.f64;
+        if (have < n) {
+            double *pad = (double *)fft->scratch;
+            memset(pad, 0, sizeof(double) * (size_t)n * 2);
+            memcpy(pad, buffer->data.f64, sizeof(double) * (size_t)have * 2);
+            iq = pad;
+        }
+        rc = fsea_exec_f64_host(plan, iq, 1, fft->row_f32);
+        if (rc != FSEA_OK) fsea_fatal("fsea_exec_f64_host", rc);
+    }
+    /* push as the newest row: the ring head moves back by one */
+    fft->ring_head = (fft->ring_head + fft->fft_history_size - 1) % fft->fft_history_size;
+    double *row = fft->buffer + (size_t)fft->ring_head * (size_t)n;
+    for (int i = 0; i < n; i++) row[i] = (double)fft->row_f32[i];
+    pthread_mutex_unlock(&fft->mutex);
+}
+
+nut_buffer *nrf_fft_get_buffer(nrf_fft *fft) {
+    const int n = fft->fft_size, h = fft->fft_history_size;
+    nut_buffer *out = nut_buffer_new_f64(n * h, 1, NULL);
+    pthread_mutex_lock(&fft->mutex);
+    const int first = h - fft->ring_head; /* rows from the head to the end of storage */
+    memcpy(out->data.f64, fft->buffer + (size_t)fft->ring_head * (size_t)n, sizeof(double) * (size_t)first * (size_t)n);
+    memcpy(out->data.f64 + (size_t)first * (size_t)n, fft->buffer, sizeof(double) * (size_t)fft->ring_head * (size_t)n);
+    pthread_mutex_unlock(&fft->mutex);
+    return out;
+}
+
+void nrf_fft_free(nrf_fft *fft) {
+    if (fft == NULL) return;
+    fsea_plan_destroy((fsea_plan *)fft->backend);
+    pthread_mutex_destroy(&fft->mutex);
+    free(fft->buffer);
+    free(fft->row_f32);
+    free(fft->scratch);
+    free(fft);
+}

@@ -1,0 +1,125 @@
+"""ctypes view of libfsea_nrf.so: the reference's nut_buffer / nrf_device / nrf_fft C API
+(include/nut.h, include/nrf.h).  Mirrors how src/main.cpp's Lua wrappers call it."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+NUT_BUFFER_U8 = 1
+NUT_BUFFER_F64 = 2
+NRF_BUFFER_SIZE_BYTES = 16 * 16384
+NRF_SAMPLES_LENGTH = 131072
+
+NUT_EXPORTS = [
+    "nut_sleep_milliseconds", "nut_buffer_new_u8", "nut_buffer_new_f64", "nut_buffer_copy",
+    "nut_buffer_reduce", "nut_buffer_clip", "nut_buffer_set_data", "nut_buffer_append",
+    "nut_buffer_get_u8", "nut_buffer_get_f64", "nut_buffer_set_u8", "nut_buffer_set_f64",
+    "nut_buffer_convert", "nut_buffer_save", "nut_buffer_free",
+]
+NRF_EXPORTS = [
+    "nrf_block_init", "nrf_block_connect", "nrf_block_process", "nrf_device_new",
+    "nrf_device_new_with_config", "nrf_device_set_frequency", "nrf_device_set_decode_handler",
+    "nrf_device_set_paused", "nrf_device_step", "nrf_device_get_samples_buffer", "nrf_device_free",
+    "nrf_fft_new", "nrf_fft_shift", "nrf_fft_process", "nrf_fft_get_buffer", "nrf_fft_free",
+]
+
+
+class NutData(ctypes.Union):
+    _fields_ = [("u8", ctypes.POINTER(ctypes.c_uint8)), ("f64", ctypes.POINTER(ctypes.c_double))]
+
+
+class NutBuffer(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int), ("length", ctypes.c_int), ("channels", ctypes.c_int),
+                ("size_bytes", ctypes.c_int), ("data", NutData)]
+
+
+NutBufferP = ctypes.POINTER(NutBuffer)
+
+
+def bind_nut(L):
+    """Attach nut_buffer_* prototypes to a loaded library (ours or the reference build)."""
+    L.nut_buffer_new_u8.restype = NutBufferP
+    L.nut_buffer_new_u8.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.nut_buffer_new_f64.restype = NutBufferP
+    L.nut_buffer_new_f64.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.nut_buffer_copy.restype = NutBufferP
+    L.nut_buffer_copy.argtypes = [NutBufferP]
+    L.nut_buffer_reduce.restype = NutBufferP
+    L.nut_buffer_reduce.argtypes = [NutBufferP, ctypes.c_double]
+    L.nut_buffer_clip.restype = NutBufferP
+    L.nut_buffer_clip.argtypes = [NutBufferP, ctypes.c_int, ctypes.c_int]
+    L.nut_buffer_set_data.restype = None
+    L.nut_buffer_set_data.argtypes = [NutBufferP, NutBufferP]
+    L.nut_buffer_append.restype = None
+    L.nut_buffer_append.argtypes = [NutBufferP, NutBufferP]
+    L.nut_buffer_get_u8.restype = ctypes.c_uint8
+    L.nut_buffer_get_u8.argtypes = [NutBufferP, ctypes.c_int]
+    L.nut_buffer_get_f64.restype = ctypes.c_double
+    L.nut_buffer_get_f64.argtypes = [NutBufferP, ctypes.c_int]
+    L.nut_buffer_set_u8.restype = None
+    L.nut_buffer_set_u8.argtypes = [NutBufferP, ctypes.c_int, ctypes.c_uint8]
+    L.nut_buffer_set_f64.restype = None
+    L.nut_buffer_set_f64.argtypes = [NutBufferP, ctypes.c_int, ctypes.c_double]
+    L.nut_buffer_convert.restype = NutBufferP
+    L.nut_buffer_convert.argtypes = [NutBufferP, ctypes.c_int]
+    L.nut_buffer_save.restype = None
+    L.nut_buffer_save.argtypes = [NutBufferP, ctypes.c_char_p]
+    L.nut_buffer_free.restype = None
+    L.nut_buffer_free.argtypes = [NutBufferP]
+    return L
+
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfsea_nrf.so")
+
+
+def nrf_lib():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError("libfsea_nrf.so is missing: run frequensea_amd.build()")
+        L = bind_nut(ctypes.CDLL(path))
+        vp = ctypes.c_void_p
+        L.nrf_device_new.restype = vp
+        L.nrf_device_new.argtypes = [ctypes.c_double, ctypes.c_char_p]
+        L.nrf_device_set_frequency.restype = ctypes.c_double
+        L.nrf_device_set_frequency.argtypes = [vp, ctypes.c_double]
+        L.nrf_device_set_paused.restype = None
+        L.nrf_device_set_paused.argtypes = [vp, ctypes.c_int]
+        L.nrf_device_step.restype = None
+        L.nrf_device_step.argtypes = [vp]
+        L.nrf_device_get_samples_buffer.restype = NutBufferP
+        L.nrf_device_get_samples_buffer.argtypes = [vp]
+        L.nrf_device_free.restype = None
+        L.nrf_device_free.argtypes = [vp]
+        L.nrf_block_connect.restype = None
+        L.nrf_block_connect.argtypes = [vp, vp]
+        L.nrf_block_process.restype = None
+        L.nrf_block_process.argtypes = [vp, NutBufferP]
+        L.nrf_fft_new.restype = vp
+        L.nrf_fft_new.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.nrf_fft_shift.restype = None
+        L.nrf_fft_shift.argtypes = [vp, ctypes.c_double]
+        L.nrf_fft_process.restype = None
+        L.nrf_fft_process.argtypes = [vp, NutBufferP]
+        L.nrf_fft_get_buffer.restype = NutBufferP
+        L.nrf_fft_get_buffer.argtypes = [vp]
+        L.nrf_fft_free.restype = None
+        L.nrf_fft_free.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def buffer_to_numpy(L, buf):
+    """Copy a nut_buffer's payload out (the buffer stays owned by the caller)."""
+    b = buf.contents
+    count = b.length * b.channels
+    if b.type == NUT_BUFFER_U8:
+        return np.ctypeslib.as_array(b.data.u8, shape=(count,)).copy()
+    return np.ctypeslib.as_array(b.data.f64, shape=(count,)).copy()

@@ -1,0 +1,144 @@
+/*
+ * fsea.h -- C ABI of libfsea_hip.so: the MI355X (gfx950) IQ-FFT spectrum path.
+ *
+ * This is the drop-in boundary.  It sits exactly where the reference calls
+ * FFTW and runs its per-sample loops on the CPU (paths under /root/reference):
+ *
+ *   fsea_plan_create      replaces fftw_plan_dft_1d + buffer setup
+ *                         src/nrf.c:562-564, c/fft-batch.c:140-145,
+ *                         c/fft-batch-broad.c:167-172
+ *   fsea_exec_u8_*        replaces byte flip + unpack/centre + fftw_execute +
+ *                         magnitude / dB pixel loops
+ *                         src/nrf.c:100-109 (flip), 599-614 (unpack, (-1)^n),
+ *                         615 (fftw_execute), 619-630 (magnitude + DC patch);
+ *                         c/fft-batch.c:62-69, 83-94; c/fft-batch-broad.c:64-71,
+ *                         106-121
+ *   fsea_exec_f64_host    the NUT_BUFFER_F64 input branch, src/nrf.c:607-609
+ *   fsea_mean_magnitude_* the 100-row "interesting?" gate,
+ *                         c/fft-batch-broad.c:81-98
+ *   fsea_composite_max_*  tile compositing, c/fft-stitch.c:46-54,
+ *                         c/fft-stitch-broad.c:28-36
+ *   fsea_plan_destroy     replaces fftw_destroy_plan/fftw_free
+ *                         src/nrf.c:637-642, c/fft-batch.c:147-152
+ *
+ * Plain C: pointers, sizes and ints only; no HIP or torch types.  Device
+ * pointers and streams cross the boundary as void* (a hipStream_t, e.g.
+ * torch.cuda.current_stream().cuda_stream).  Every function returns 0 on
+ * success or a negative FSEA_E* code; fsea_last_error_string() describes the
+ * last failure on the calling thread.  There is no CPU fallback: without a
+ * usable gfx950 device plan creation fails with FSEA_ENODEVICE.
+ */
+#ifndef FSEA_H
+#define FSEA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fsea_plan fsea_plan;
+
+/* Epilogue modes.  Output element type and row length are per mode. */
+enum {
+    /* sqrt(re^2+im^2) as f32, bin n/2 := bin n/2-1 (src/nrf.c:619-630). */
+    FSEA_MODE_MAG_F32 = 0,
+    /* clamp_u8(trunc(10*log10(re^2+im^2+1e-20)*10)) (c/fft-batch.c:83-94). */
+    FSEA_MODE_DB10_U8 = 1,
+    /* same with *5 and pixel n/2 := pixel n/2-1 (c/fft-batch-broad.c:106-121). */
+    FSEA_MODE_DB5_U8_DCFIX = 2,
+    /* the complex spectrum itself, interleaved f32 re,im (what fft_out holds). */
+    FSEA_MODE_COMPLEX_F32 = 3,
+    /* magnitude without the DC patch. */
+    FSEA_MODE_MAG_NODC_F32 = 4,
+    /* 10*log10(re^2+im^2+1e-20) as f32 (log-magnitude, no quantisation). */
+    FSEA_MODE_DB_F32 = 5
+};
+
+enum {
+    FSEA_OK = 0,
+    FSEA_EINVAL = -1,    /* bad argument (size, hop, alignment, mode) */
+    FSEA_ENODEVICE = -2, /* no usable gfx950 device / HIP runtime failure at init */
+    FSEA_ENOMEM = -3,
+    FSEA_EHIP = -4       /* a HIP call failed; see fsea_last_error_string() */
+};
+
+/* Number of visible HIP devices (0 and FSEA_ENODEVICE when there are none). */
+int fsea_device_count(int *count);
+
+/* fft_size: power of two, 128 <= fft_size <= 16384.
+ * hop: samples between successive frame starts (hop == fft_size: back-to-back
+ * frames as in c/fft-batch.c; hop < fft_size: overlapped STFT).  hop must be a
+ * positive multiple of 8.
+ * device: HIP device ordinal. */
+int fsea_plan_create(fsea_plan **plan, int fft_size, int hop, int mode, int device);
+int fsea_plan_destroy(fsea_plan *plan);
+
+/* Tuning hook: same as fsea_plan_create but selects a named kernel variant for
+ * the size ("" = the default).  Unknown variants fail with FSEA_EINVAL. */
+int fsea_plan_create_variant(fsea_plan **plan, int fft_size, int hop, int mode, int device,
+                             const char *variant);
+
+/* Launch geometry the plan would use for n_frames (persistent grid, workgroup
+ * size, static LDS bytes per workgroup).  Any out-pointer may be NULL. */
+int fsea_plan_grid(const fsea_plan *plan, size_t n_frames, unsigned *grid, unsigned *block,
+                   size_t *lds_bytes);
+
+/* Bytes of one output row for the plan's mode (fft_size * element size). */
+size_t fsea_plan_row_bytes(const fsea_plan *plan);
+int fsea_plan_fft_size(const fsea_plan *plan);
+
+/* Device-resident execution.  d_iq: device pointer to interleaved 8-bit IQ,
+ * at least 2*((n_frames-1)*hop + fft_size) bytes, 16-byte aligned.
+ * flip != 0: bytes are raw HackRF int8 and the kernel applies b ^ 0x80
+ * (src/nrf.c:103-106); flip == 0: bytes are already offset-binary (RTL-SDR).
+ * d_out: device pointer, n_frames rows of fsea_plan_row_bytes().
+ * stream: hipStream_t as void*, or NULL for the plan's own stream.
+ * Asynchronous with respect to the host. */
+int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
+                        void *d_out, void *stream);
+
+/* Host-buffer execution: copies through pinned staging, runs, copies back,
+ * returns when `out` is complete. */
+int fsea_exec_u8_host(fsea_plan *plan, const uint8_t *iq, size_t n_frames, int flip,
+                      void *out);
+
+/* F64 interleaved complex input (src/nrf.c:607-609: no /256, no flip). */
+int fsea_exec_f64_host(fsea_plan *plan, const double *iq, size_t n_frames, void *out);
+
+/* Mean of sqrt(re^2+im^2) over the first n_frames rows of a device-resident
+ * u8 IQ block (c/fft-batch-broad.c:81-98).  Synchronous. */
+int fsea_mean_magnitude_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
+                                  int flip, double *mean, void *stream);
+
+/* dst[y][dst_x + j] = max(dst, src[y][j]) for a width x height u8 tile
+ * (c/fft-stitch.c:46-54).  Device pointers; asynchronous on `stream`. */
+int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x,
+                              uint32_t dst_y, uint32_t width, uint32_t height,
+                              uint32_t dst_stride, uint32_t src_stride, int device,
+                              void *stream);
+
+/* Small device-memory helpers so that C callers need no HIP headers. */
+int fsea_device_alloc(int device, size_t bytes, void **d_ptr);
+int fsea_device_free(int device, void *d_ptr);
+int fsea_copy_to_device(int device, void *d_dst, const void *src, size_t bytes);
+int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes);
+int fsea_stream_synchronize(fsea_plan *plan, void *stream);
+
+/* Measurement helper: runs fsea_exec_u8_device `reps` times back to back on
+ * `stream` between two HIP events recorded on that same stream and returns the
+ * average milliseconds per launch. */
+int fsea_time_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
+                             int flip, void *d_out, void *stream, int reps,
+                             float *avg_ms);
+
+/* Name of the kernel variant the plan launches (for matching rocprof rows). */
+const char *fsea_plan_kernel_name(const fsea_plan *plan);
+
+const char *fsea_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

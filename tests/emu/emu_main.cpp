@@ -1,0 +1,76 @@
+// TEST-ONLY: runs the real kernel body (fsea_fft_core.h) on the CPU, see hip/hip_runtime.h.
+#include <hip/hip_runtime.h>
+
+#include <barrier>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "fsea_configs.h"
+#include "fsea_fft_core.h"
+#include "fsea_tables.h"
+
+thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+static thread_local std::barrier<> *g_barrier = nullptr;
+void emu_syncthreads() { g_barrier->arrive_and_wait(); }
+
+template <class Cfg, int IN, int MODE_T>
+static void run_grid(fsea::FftArgs a, unsigned grid) {
+    std::vector<fsea::TwPair> tw;
+    size_t off[4];
+    const int radix[4] = {Cfg::R(0), Cfg::R(1), Cfg::R(2), Cfg::R(3)};
+    fsea::build_twiddles(Cfg::NP, radix, tw, off);
+    for (int i = 0; i < 4; ++i) a.tw[i] = reinterpret_cast<const float2 *>(tw.data()) + off[i];
+    for (unsigned b = 0; b < grid; ++b) {
+        std::vector<float2> lds_store(Cfg::LDS_TOTAL + 2);
+        float2 *lds = lds_store.data();
+        if (reinterpret_cast<uintptr_t>(lds) & 15) lds += 1;  // 16-byte alignment as on the device
+        std::barrier<> bar(Cfg::WG);
+        std::vector<std::thread> th;
+        for (int t = 0; t < Cfg::WG; ++t) {
+            th.emplace_back([&, t] {
+                threadIdx.x = (unsigned)t;
+                blockIdx.x = b;
+                blockDim.x = Cfg::WG;
+                gridDim.x = grid;
+                g_barrier = &bar;
+                fsea::FftKernel<Cfg, IN, MODE_T>::run(a, lds);
+            });
+        }
+        for (auto &x : th) x.join();
+    }
+}
+
+template <class Cfg>
+static int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsigned grid) {
+    if (in_kind == fsea::IN_U8 && mode_t == 0) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
+    else if (in_kind == fsea::IN_U8) run_grid<Cfg, fsea::IN_U8, -1>(a, grid);
+    else run_grid<Cfg, fsea::IN_F32, -1>(a, grid);
+    return 0;
+}
+
+// n: transform size; in_kind 0 = u8 IQ, 1 = f32 complex; specialised != 0 selects the
+// compile-time MAG kernel; grid = number of emulated workgroups.
+extern "C" int emu_fft(int n, int in_kind, int specialised, const void *in, void *out, size_t n_frames, size_t hop,
+                       int flip, int mode, unsigned grid) {
+    fsea::FftArgs a;
+    a.in = in;
+    a.out = out;
+    a.n_frames = n_frames;
+    a.hop = hop;
+    a.xormask = flip ? 0u : 0x80808080u;
+    a.mode = mode;
+    const int mt = (specialised && mode == fsea::MODE_MAG && in_kind == fsea::IN_U8) ? 0 : -1;
+    switch (n) {
+    case 128: return dispatch<fsea::FftCfg<FSEA_CFG_128>>(in_kind, mt, a, grid);
+    case 256: return dispatch<fsea::FftCfg<FSEA_CFG_256>>(in_kind, mt, a, grid);
+    case 512: return dispatch<fsea::FftCfg<FSEA_CFG_512>>(in_kind, mt, a, grid);
+    case 1024: return dispatch<fsea::FftCfg<FSEA_CFG_1024>>(in_kind, mt, a, grid);
+    case 2048: return dispatch<fsea::FftCfg<FSEA_CFG_2048>>(in_kind, mt, a, grid);
+    case 4096: return dispatch<fsea::FftCfg<FSEA_CFG_4096>>(in_kind, mt, a, grid);
+    case 8192: return dispatch<fsea::FftCfg<FSEA_CFG_8192>>(in_kind, mt, a, grid);
+    case 16384: return dispatch<fsea::FftCfg<FSEA_CFG_16384>>(in_kind, mt, a, grid);
+    default: return -1;
+    }
+}

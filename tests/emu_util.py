@@ -1,0 +1,41 @@
+"""Builds and drives tests/emu/libfsea_emu.so: the real kernel source compiled for the CPU
+(TEST-ONLY; see tests/emu/hip/hip_runtime.h)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from tests.conftest import ROOT
+
+_EMU = None
+OUT_DTYPE = {0: np.float32, 1: np.uint8, 2: np.uint8, 3: np.complex64, 4: np.float32, 5: np.float32}
+
+
+def emu_lib():
+    global _EMU
+    if _EMU is None:
+        src = os.path.join(ROOT, "tests", "emu", "emu_main.cpp")
+        out = os.path.join(ROOT, "tests", "emu", "libfsea_emu.so")
+        csrc = os.path.join(ROOT, "frequensea_amd", "csrc")
+        deps = [src, os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")] + [
+            os.path.join(csrc, f) for f in ("fsea_fft_core.h", "fsea_configs.h", "fsea_tables.h")]
+        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            subprocess.check_call(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread",
+                                   "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu"),
+                                   "-I" + csrc, src, "-o", out])
+        L = ctypes.CDLL(out)
+        L.emu_fft.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+        _EMU = L
+    return _EMU
+
+
+def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0):
+    hop = n if hop is None else hop
+    src = np.ascontiguousarray(iq)
+    out = np.zeros((n_frames, n), dtype=OUT_DTYPE[mode])
+    rc = emu_lib().emu_fft(n, in_kind, int(specialised), src.ctypes.data, out.ctypes.data, n_frames, hop,
+                           int(bool(flip)), mode, grid)
+    assert rc == 0
+    return out

@@ -1,0 +1,101 @@
+"""CPU tier: the kernel source of frequensea_amd/csrc/fsea_fft_core.h, compiled by g++ through
+the test-only shim in tests/emu, against the oracle.  Catches index-arithmetic errors (Stockham
+addressing, LDS padding, twiddle tables, epilogue bin ownership, frame mapping) without a GPU.
+The GPU tier (test_gpu_parity.py) repeats these checks on the real device."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import parity
+from tests.conftest import GOLDEN_KEYS, synth_iq
+from tests.emu_util import emu_rows
+
+SIZES = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+
+
+def frames_for(n):
+    return 70 if n <= 512 else (19 if n <= 2048 else 5)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_mag_all_sizes(n):
+    nf = frames_for(n)                      # not a multiple of frames-per-workgroup: ragged tail
+    iq = synth_iq(n, 2 * nf * n)
+    got = emu_rows(iq, n, nf, grid=2)
+    parity.check_mode(got, iq, n, nf, n, True, 0)
+    assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])      # DC patch
+
+
+@pytest.mark.parametrize("n", [128, 1024, 4096, 8192])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+def test_all_modes_runtime_dispatch(n, mode):
+    nf = 9 if n <= 1024 else 3
+    iq = synth_iq(100 + n + mode, 2 * nf * n)
+    got = emu_rows(iq, n, nf, mode=mode, grid=1, specialised=False)
+    parity.check_mode(got, iq, n, nf, n, True, mode)
+
+
+@pytest.mark.parametrize("n,hop", [(256, 128), (1024, 512), (1024, 8), (8192, 4096), (16384, 8192)])
+def test_overlapped_hop(n, hop):
+    nf = 11 if n <= 1024 else 4
+    iq = synth_iq(7 * n + hop, 2 * ((nf - 1) * hop + n))
+    got = emu_rows(iq, n, nf, hop=hop, grid=3)
+    parity.check_mode(got, iq, n, nf, hop, True, 0)
+
+
+@pytest.mark.parametrize("n", [256, 2048, 8192])
+def test_no_flip_rtlsdr_style(n):
+    nf = 6
+    iq = synth_iq(5 * n, 2 * nf * n) ^ np.uint8(0x80)     # already offset binary
+    for mode in (0, 1):
+        got = emu_rows(iq, n, nf, flip=False, mode=mode, specialised=(mode == 0))
+        parity.check_mode(got, iq, n, nf, n, False, mode)
+
+
+@pytest.mark.parametrize("grid", [1, 2, 8, 16])
+def test_grid_mappings_cover_every_frame(grid):
+    n, nf = 1024, 53
+    iq = synth_iq(grid, 2 * nf * n)
+    got = emu_rows(iq, n, nf, grid=grid)
+    parity.check_mode(got, iq, n, nf, n, True, 0)
+
+
+@pytest.mark.parametrize("n", [128, 1024, 4096])
+def test_f32_complex_input(n):
+    """The NUT_BUFFER_F64 branch of nrf_fft_process (src/nrf.c:607-609) arrives as f32 pairs."""
+    nf = 5
+    rng = np.random.default_rng(n)
+    x = rng.normal(0, 0.2, 2 * nf * n)
+    got = emu_rows(x.astype(np.float32), n, nf, mode=0, in_kind=1, specialised=False)
+    spec = np.stack([O.fft_forward(O.unpack_center_f64(x[2 * f * n: 2 * (f + 1) * n])) for f in range(nf)])
+    want = np.stack([O.mag_row(s) for s in spec])
+    parity.check_float(got, want)
+    gotc = emu_rows(x.astype(np.float32), n, nf, mode=3, in_kind=1, specialised=False)
+    parity.check_float(gotc, spec)
+
+
+@pytest.mark.parametrize("key", GOLDEN_KEYS)
+@pytest.mark.parametrize("n", [256, 1024, 8192])
+def test_recorded_captures(golden, key, n):
+    raw = golden[key + "__raw"]
+    got = emu_rows(raw, n, 1, grid=1)
+    parity.check_float(got[0], golden["%s__mag_%d" % (key, n)])
+    px = emu_rows(raw, n, 1, mode=1, grid=1, specialised=False)
+    parity.check_u8(px[0], golden["%s__db10_%d" % (key, n)])
+    px = emu_rows(raw, n, 1, mode=2, grid=1, specialised=False)
+    parity.check_u8(px[0], golden["%s__db5_%d" % (key, n)])
+
+
+def test_edge_inputs():
+    n = 1024
+    # constant input: only the (patched-away) DC bin is non-zero
+    z = np.zeros(2 * n, np.uint8)
+    assert emu_rows(z, n, 1).max() < 1e-4
+    spec = emu_rows(z, n, 1, mode=3, specialised=False)[0]
+    assert abs(abs(spec[n // 2]) - 0.5 * n * np.sqrt(2)) < 1e-3 and np.abs(np.delete(spec, n // 2)).max() < 1e-4
+    # full-scale extremes
+    ext = np.tile(np.array([0x7f, 0x80, 0x80, 0x7f], np.uint8), n // 2)
+    got = emu_rows(ext, n, 1)
+    parity.check_mode(got, ext, n, 1, n, True, 0)
+    # zero frames: nothing is written
+    assert emu_rows(z, n, 0).shape == (0, n)
