@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X IQ-FFT spectrum path on BASELINE.json's headline config.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (u8 IQ -> flip -> (-1)^n -> FFT -> |X| + DC patch) over one
+batch of synthetic int8 IQ that is already resident in HBM: by default BASELINE.json configs[2],
+"Batched 8192-pt FFT, 4096 frames synthetic uint8 IQ, 1 MI355X (HBM-bound roofline run)".
+Successive steps rotate through several independent input/output buffer sets (each 192 MiB) so
+that no step can be served from the 256 MiB Infinity Cache.  With N > 1 (one process per GPU,
+launched by torch.distributed.run) every rank transforms its own batch -- whole frames shard
+across GPUs with no data-path collective -- and `value` is the aggregate over all ranks (weak
+scaling).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel vs the HBM roofline: algorithmic bytes per launch
+                (2*hop + 4*N per frame) / average launch duration measured with HIP events on
+                the launch stream over the timed region.
+  cpu_baseline  the oracle's reference-shaped CPU loop (oracle/fsea_oracle.c, kind "port";
+                FFTW is not installed in this image) timed on this host's cores on a bounded
+                sample of the same workload.  A reported baseline, not the target.
+  extra         the same measurement at N=1024 (the other size BASELINE.json's metric names).
+
+PyTorch is plumbing only here: device buffers, streams, torch.distributed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (fft_size, frames per batch, hop)
+    "batch8192x4096": (8192, 4096, 8192),
+    "batch1024x32768": (1024, 32768, 1024),
+    "batch4096x8192": (4096, 8192, 4096),
+    "stft16384x8191": (16384, 8191, 8192),
+}
+
+
+def synth_batch(seed, n_bytes):
+    """HackRF-style int8 IQ: Gaussian sigma=20 + complex tone at +fs/8, amp 40."""
+    rng = np.random.default_rng(seed)
+    n = n_bytes // 2
+    out = np.empty(2 * n, dtype=np.int8)
+    chunk = 1 << 22
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        t = np.arange(s, e, dtype=np.float64)
+        ph = 2 * np.pi * 0.125 * t
+        i = rng.normal(0, 20, e - s) + 40 * np.cos(ph)
+        q = rng.normal(0, 20, e - s) + 40 * np.sin(ph)
+        out[2 * s:2 * e:2] = np.clip(np.rint(i), -128, 127)
+        out[2 * s + 1:2 * e:2] = np.clip(np.rint(q), -128, 127)
+    return out.view(np.uint8)
+
+
+def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
+    from frequensea_amd import fsea
+
+    n, frames, hop = WORKLOADS[workload]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_MAG_F32, device=dev.index)
+    in_bytes = plan.in_bytes(frames)
+    host = synth_batch(3 + 1000 * rank, in_bytes)
+    ins, outs = [], []
+    for s in range(sets):
+        t_in = torch.from_numpy(np.roll(host, 2 * 8 * s)).to(dev)   # distinct contents per set
+        ins.append(t_in)
+        outs.append(torch.empty(frames * n, dtype=torch.float32, device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        s = k % sets
+        plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=stream)
+
+    for k in range(warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(steps):
+        step(warmup + k)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / steps          # events on the launch stream
+    if dist is not None:
+        tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(tt[0]), float(tt[1])
+    sample = outs[0][: 4 * n].cpu().numpy().reshape(4, n)
+    kname = plan.kernel_name
+    grid = plan.grid(frames)
+    plan.close()
+    return dict(n=n, frames=frames, hop=hop, wall=wall, kernel_ms=kernel_ms, kernel=kname, grid=grid,
+                sample=sample, host_head=np.roll(host, 0)[: 2 * 4 * hop + 2 * n])
+
+
+def cpu_baseline(n, hop, cores, budget_s):
+    """Oracle port timed on this host (bounded sample: about `budget_s` core-seconds)."""
+    from oracle import oracle as O
+
+    probe_frames = 32
+    buf_frames = 2048                                        # 32 MiB at N=8192; reused cyclically
+    iq = synth_batch(3, 2 * ((buf_frames - 1) * hop + n))
+    t = O.time_mag_rows(iq, probe_frames, n, hop)            # 1 thread calibration
+    per_frame = max(t / probe_frames, 1e-7)
+    reps = int(max(1, round(budget_s / per_frame / buf_frames)))
+    frames = reps * buf_frames
+    t1 = O.time_mag_rows(iq, min(buf_frames, max(64, int(2.0 / per_frame))), n, hop)
+    one_thread = min(buf_frames, max(64, int(2.0 / per_frame))) / t1
+    tm = 0.0
+    for _ in range(reps):
+        tm += O.time_mag_rows(iq, buf_frames, n, hop, threads=cores)
+    return dict(value=frames / tm, unit="frames/s", cores=cores, kind="port",
+                sample="%d frames (%d passes over a %d-frame synthetic N=%d batch; oracle/fsea_oracle.c radix-2 "
+                       "f64 FFT, frames sharded over %d threads, one plan per thread; FFTW not installed)"
+                       % (frames, reps, buf_frames, n, cores),
+                one_thread=one_thread)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="batch8192x4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=16.0, help="core-seconds for the CPU sample")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+    if args.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    res = run_gpu(args, args.workload, rank, world, dist, torch, args.steps, args.warmup, args.sets)
+    n, frames, hop = res["n"], res["frames"], res["hop"]
+    value = world * frames * args.steps / res["wall"]
+    alg_bytes = (2 * hop + 4 * n) * frames                      # 2*hop read + 4*N written
+    achieved = alg_bytes / (res["kernel_ms"] * 1e-3) / 1e9
+    line = {
+        "metric": "fft_frames_per_sec_n%d" % n,
+        "value": value,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * res["wall"] / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "msamples_per_sec": value * hop / 1e6,
+        "config": {"workload": "%s: batched %d-pt FFT, %d frames per GPU per step, int8 IQ resident in HBM, "
+                               "MAG_F32 epilogue (nrf_fft_process semantics)" % (args.workload, n, frames),
+                   "fft_size": n, "frames_per_step_per_gpu": frames, "hop": hop,
+                   "buffer_sets": args.sets, "parallelism": "frames sharded x%d, no collective" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": res["kernel"], "avg_launch_ms": res["kernel_ms"],
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "read_only_frac": (2 * hop * frames) / (res["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "grid_block_lds": list(res["grid"])},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file))
+            if tr.get("kernel") == res["kernel"] and tr.get("frames") == frames:
+                line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if rank == 0:
+        # correctness guard on what was just timed (oracle = checker only)
+        from oracle import oracle as O
+        want = O.rows(res["host_head"], 4, n, hop=hop)
+        rel = float(np.linalg.norm(res["sample"] - want) / np.linalg.norm(want))
+        line["parity_rel_l2_first_rows"] = rel
+        if not rel <= 1e-6:
+            raise SystemExit("bench: GPU rows differ from the oracle (rel %.3e)" % rel)
+
+    if world == 1 and not args.no_extra and args.workload == "batch8192x4096":
+        ex = run_gpu(args, "batch1024x32768", rank, world, dist, torch, args.steps, args.warmup, args.sets)
+        exb = (2 * ex["hop"] + 4 * ex["n"]) * ex["frames"]
+        line["extra"] = {"fft_frames_per_sec_n1024": ex["frames"] * args.steps / ex["wall"],
+                         "msamples_per_sec_n1024": ex["frames"] * args.steps / ex["wall"] * ex["hop"] / 1e6,
+                         "roofline_frac_n1024": exb / (ex["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "kernel_n1024": ex["kernel"], "avg_launch_ms_n1024": ex["kernel_ms"]}
+
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        cb = cpu_baseline(n, hop, cores, args.cpu_budget)
+        line["cpu_baseline"] = cb
+        line["gpu_over_cpu_all_cores"] = value / cb["value"]
+
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

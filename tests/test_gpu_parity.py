@@ -1,0 +1,301 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI of libfsea_hip.so and through the
+reference-shaped nrf_fft API of libfsea_nrf.so, against the f64 oracle, the committed golden
+vectors from the reference's recorded captures, and -- at BASELINE.json's full sizes -- through
+size-independent properties (Parseval, tone position, sampled rows).  Tolerances: tests/parity.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from frequensea_amd import fsea, nrf
+from oracle import oracle as O
+from tests import parity
+from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, synth_iq
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+
+
+class DeviceBuffer:
+    def __init__(self, nbytes, device=0):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = nbytes
+        self.device = device
+        fsea._check(fsea.hip_lib().fsea_device_alloc(device, nbytes, ctypes.byref(self.ptr)))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        fsea._check(fsea.hip_lib().fsea_copy_to_device(self.device, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        fsea._check(fsea.hip_lib().fsea_copy_to_host(self.device, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            fsea.hip_lib().fsea_device_free(self.device, self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+
+def test_device_present_and_library_loaded():
+    assert fsea.device_count() >= 1
+    p = fsea.Plan(8192)
+    assert p.kernel_name == "fsea_fft8192_u8_mag"
+    grid, block, lds = p.grid(4096)
+    assert block == 256 and grid >= 256 and grid % 8 == 0 and lds > 64 * 1024
+    p.close()
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_mag_rows_all_sizes(n):
+    nf = 300 if n <= 1024 else 37
+    iq = synth_iq(n, 2 * nf * n)
+    plan = fsea.Plan(n)
+    got = plan.exec_host(iq, nf)
+    parity.check_mode(got, iq, n, nf, n, True, 0)
+    assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
+    plan.close()
+
+
+@pytest.mark.parametrize("n", [128, 1024, 4096, 8192, 16384])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+def test_other_modes(n, mode):
+    nf = 33
+    iq = synth_iq(1000 + n + mode, 2 * nf * n)
+    plan = fsea.Plan(n, mode=mode)
+    got = plan.exec_host(iq, nf)
+    parity.check_mode(got, iq, n, nf, n, True, mode)
+    plan.close()
+
+
+@pytest.mark.parametrize("n,hop", [(256, 128), (1024, 8), (4096, 2048), (16384, 8192)])
+def test_overlapped_frames(n, hop):
+    nf = 41
+    iq = synth_iq(3 * n + hop, 2 * ((nf - 1) * hop + n))
+    plan = fsea.Plan(n, hop=hop)
+    got = plan.exec_host(iq, nf)
+    parity.check_mode(got, iq, n, nf, hop, True, 0)
+    plan.close()
+
+
+def test_flip_is_bit_exact_identity():
+    """flip=1 on raw int8 bytes and flip=0 on the same bytes ^ 0x80 must give identical bits."""
+    n, nf = 1024, 64
+    raw = synth_iq(5, 2 * nf * n)
+    plan = fsea.Plan(n, mode=fsea.MODE_COMPLEX_F32)
+    a = plan.exec_host(raw, nf, flip=True)
+    b = plan.exec_host(raw ^ np.uint8(0x80), nf, flip=False)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    plan.close()
+
+
+@pytest.mark.parametrize("key", GOLDEN_KEYS)
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
+def test_recorded_captures_match_golden(golden, key, n):
+    raw = golden[key + "__raw"]
+    for mode, name in [(0, "mag"), (1, "db10"), (2, "db5")]:
+        plan = fsea.Plan(n, mode=mode)
+        got = plan.exec_host(raw, 1)[0]
+        want = golden["%s__%s_%d" % (key, name, n)]
+        if mode == 0:
+            parity.check_float(got, want)
+        else:
+            parity.check_u8(got, want)
+        plan.close()
+
+
+def test_survey_known_answers_on_gpu(golden):
+    raw = golden["rf_100p900_1__raw"]
+    row = fsea.Plan(1024).exec_host(raw, 1)[0]
+    assert row.argmax() == 513 and abs(float(row.max()) - 37.935861) < 1e-4
+    assert abs(float(row.astype(np.float64).sum()) - 1567.312172) < 1e-2
+    row = fsea.Plan(8192).exec_host(raw, 1)[0]
+    assert row.argmax() == 3358 and abs(float(row.max()) - 162.437851) < 5e-4
+
+
+def test_device_resident_and_ragged_counts():
+    n = 2048
+    plan = fsea.Plan(n)
+    for nf in (1, 3, 4, 5, 1023):
+        iq = synth_iq(nf, 2 * nf * n)
+        d_in = DeviceBuffer(iq.nbytes).upload(iq)
+        d_out = DeviceBuffer(nf * n * 4)
+        plan.exec_device(d_in.ptr, nf, d_out.ptr)
+        plan.synchronize()
+        got = d_out.download(np.float32, (nf, n))
+        parity.check_mode(got, iq, n, nf, n, True, 0)
+        d_in.free()
+        d_out.free()
+    plan.close()
+
+
+def test_f64_input_branch():
+    n, nf = 1024, 7
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 0.2, 2 * nf * n)
+    plan = fsea.Plan(n)
+    got = plan.exec_host_f64(x, nf)
+    want = np.stack([O.mag_row(O.fft_forward(O.unpack_center_f64(x[2 * f * n: 2 * (f + 1) * n])))
+                     for f in range(nf)])
+    parity.check_float(got, want)
+    plan.close()
+
+
+def test_invalid_arguments_are_reported():
+    plan = fsea.Plan(1024)
+    L = fsea.hip_lib()
+    d = DeviceBuffer(4096)
+    assert L.fsea_exec_u8_device(plan._p, d.ptr.value + 2, 1, 1, d.ptr, None) == -1
+    assert b"aligned" in L.fsea_last_error_string()
+    assert L.fsea_exec_u8_device(plan._p, None, 1, 1, d.ptr, None) == -1
+    d.free()
+    plan.close()
+
+
+@pytest.mark.parametrize("n,nf", [(8192, 4096), (1024, 32768), (4096, 8192)])
+def test_full_size_properties(n, nf):
+    """BASELINE.json sizes: Parseval on every row, tone position, and 24 sampled rows vs the
+    oracle (the oracle would need minutes for all of them)."""
+    iq = synth_iq(3, 2 * nf * n)                      # seed 3 = SURVEY 8(d) config C3
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_out = DeviceBuffer(nf * n * 4)
+    plan = fsea.Plan(n, mode=fsea.MODE_MAG_NODC_F32)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    mag = d_out.download(np.float32, (nf, n)).astype(np.float64)
+    u = (iq ^ np.uint8(0x80)).astype(np.float64).reshape(nf, 2 * n) / 256.0
+    energy_in = n * np.sum(u * u, axis=1)
+    energy_out = np.sum(mag * mag, axis=1)
+    assert np.max(np.abs(energy_out - energy_in) / energy_in) < 2e-6          # Parseval per row
+    # the +fs/8 tone lands at bin N/2 + N/8 in every row (below only the DC bin N/2)
+    no_dc = mag.copy()
+    no_dc[:, n // 2] = 0
+    assert np.all(no_dc.argmax(axis=1) == n // 2 + n // 8)
+    plan.close()
+    plan = fsea.Plan(n)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    got = d_out.download(np.float32, (nf, n))
+    rows = np.unique(np.r_[0, 1, nf - 1, np.random.default_rng(n).integers(0, nf, 21)])
+    for f in rows:
+        want = O.rows(iq[2 * f * n: 2 * (f + 1) * n], 1, n)[0]
+        parity.check_float(got[f], want)
+    # MAG == MAG_NODC everywhere except the patched bin
+    keep = np.ones(n, bool)
+    keep[n // 2] = False
+    assert np.array_equal(got[:, keep], mag[:, keep].astype(np.float32))
+    d_in.free()
+    d_out.free()
+    plan.close()
+
+
+def test_mean_magnitude_gate_and_composite():
+    n, nf = 256, 100                                    # c/fft-batch-broad.c: 256-pt, 100-row gate
+    iq = synth_iq(9, 2 * nf * n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    plan = fsea.Plan(n, mode=fsea.MODE_DB5_U8_DCFIX)
+    mean = plan.mean_magnitude_device(d_in.ptr, nf)
+    want = O.mean_magnitude(O.rows(iq, nf, n, mode=O.MODE_COMPLEX))
+    assert abs(mean - want) <= 2e-6 * want
+    # tiles -> stitched image, 50 % overlap as c/fft-stitch.c (bit-exact integer max)
+    tiles = [np.random.default_rng(k).integers(0, 256, (64, n), dtype=np.uint8) for k in range(3)]
+    width = n + 2 * (n // 2)
+    want_img = np.zeros((64, width), np.uint8)
+    d_img = DeviceBuffer(want_img.nbytes).upload(want_img)
+    for k, t in enumerate(tiles):
+        O.composite_max(want_img, t, k * (n // 2))
+        d_t = DeviceBuffer(t.nbytes).upload(t)
+        fsea.composite_max_device(d_img.ptr, d_t.ptr, k * (n // 2), 0, n, 64, width, n)
+        d_t.free()                                      # hipFree synchronises the device
+    got_img = d_img.download(np.uint8, want_img.shape)
+    assert np.array_equal(got_img, want_img)
+    d_in.free()
+    d_img.free()
+    plan.close()
+
+
+# ---- the reference-shaped API (what lua/fft.lua drives through src/main.cpp) -------------
+
+def _nut_u8(L, arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    return L.nut_buffer_new_u8(arr.size // 2, 2, arr.ctypes.data)
+
+
+def test_nrf_fft_api_history_and_shift(golden):
+    L = nrf.nrf_lib()
+    n, h = 256, 4
+    fft = L.nrf_fft_new(n, h)
+    keys = GOLDEN_KEYS
+    for key in keys:                                    # four process calls, newest row first
+        flipped = golden[key + "__flipped"]             # device buffers are offset binary
+        buf = _nut_u8(L, flipped)
+        L.nrf_fft_process(fft, buf)
+        L.nut_buffer_free(buf)
+    out = L.nrf_fft_get_buffer(fft)
+    c = out.contents
+    assert (c.type, c.length, c.channels, c.size_bytes) == (nrf.NUT_BUFFER_F64, n * h, 1, 8 * n * h)
+    hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+    L.nut_buffer_free(out)
+    want = np.stack([golden[k + "__mag_256"] for k in reversed(keys)])
+    parity.check_float(hist, want)
+    # shifts: compare with the oracle applied to the same history (exact copies of doubles)
+    for d in (8.0, -8.0, 50.0, -3.0, 0.5, 1e9):
+        ref = hist.copy() if d == 8.0 else ref
+        O.fft_shift(ref, n, h, d)
+        L.nrf_fft_shift(fft, d)
+        out = L.nrf_fft_get_buffer(fft)
+        now = nrf.buffer_to_numpy(L, out).reshape(h, n)
+        L.nut_buffer_free(out)
+        assert np.array_equal(now, ref), d
+    L.nrf_fft_free(fft)
+
+
+def test_nrf_fft_lua_sizes_and_f64_input(golden):
+    """The sizes the shipped Lua scenes use: (1024,1024) fft.lua:34, (128,512) fft-sea.lua:211."""
+    L = nrf.nrf_lib()
+    raw = golden["rf_202p500_2__flipped"]
+    for n, h in ((1024, 1024), (128, 512)):
+        fft = L.nrf_fft_new(n, h)
+        buf = _nut_u8(L, raw)
+        for _ in range(3):
+            L.nrf_fft_process(fft, buf)
+        out = L.nrf_fft_get_buffer(fft)
+        hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+        L.nut_buffer_free(out)
+        want = golden["rf_202p500_2__mag_%d" % n]
+        for r in range(3):
+            parity.check_float(hist[r], want)
+        assert not hist[3:].any()
+        # f64 input (nrf_freq_shifter output feeds nrf_fft in lua/fft-shifted.lua:52-55)
+        f64 = L.nut_buffer_convert(buf, nrf.NUT_BUFFER_F64)
+        L.nrf_fft_process(fft, f64)
+        out = L.nrf_fft_get_buffer(fft)
+        parity.check_float(nrf.buffer_to_numpy(L, out).reshape(h, n)[0], want)
+        L.nut_buffer_free(out)
+        L.nut_buffer_free(f64)
+        L.nut_buffer_free(buf)
+        L.nrf_fft_free(fft)
+
+
+def test_block_graph_device_to_fft(tmp_path):
+    """nrf_block_connect(device, fft): the replay thread pushes rows (src/nrf.c:37-50,118)."""
+    import time
+    L = nrf.nrf_lib()
+    raw = synth_iq(21, nrf.NRF_BUFFER_SIZE_BYTES)
+    path = tmp_path / "one.raw"
+    raw.tofile(path)
+    fft = L.nrf_fft_new(1024, 8)
+    dev = L.nrf_device_new(100.0, str(path).encode())
+    L.nrf_block_connect(dev, fft)
+    time.sleep(0.3)
+    L.nrf_device_free(dev)
+    out = L.nrf_fft_get_buffer(fft)
+    hist = nrf.buffer_to_numpy(L, out).reshape(8, 1024)
+    L.nut_buffer_free(out)
+    want = O.rows(raw, 1, 1024)[0]
+    assert hist[0].any()
+    parity.check_float(hist[0], want)
+    L.nrf_fft_free(fft)

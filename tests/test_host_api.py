@@ -1,0 +1,168 @@
+"""CPU tier: the C host layer (libfsea_nrf.so) and the C-ABI library load and export every
+symbol the headers declare; nut_buffer semantics are checked against the reference's own
+src/nut.c (oracle/_ref/libnut_ref.so) when that build exists; the file-replay device needs no
+GPU.  No GPU compute is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import frequensea_amd
+from frequensea_amd import fsea, nrf
+from tests.conftest import ROOT, synth_iq
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b((?:fsea|nut|nrf)_[a-z0-9_]+)\s*\(", text))
+
+
+def test_fsea_exports_every_declared_symbol():
+    L = ctypes.CDLL(fsea.lib_path())
+    names = declared_functions("fsea.h")
+    assert names == set(fsea.EXPORTS)
+    for name in names:
+        assert hasattr(L, name), name
+
+
+def test_nrf_exports_every_declared_symbol():
+    L = ctypes.CDLL(nrf.lib_path())
+    for header, listed in (("nut.h", nrf.NUT_EXPORTS), ("nrf.h", nrf.NRF_EXPORTS)):
+        names = {n for n in declared_functions(header) if not n.endswith("_fn")}
+        assert names == set(listed), names ^ set(listed)
+        for name in names:
+            assert hasattr(L, name), name
+
+
+def test_no_gpu_fails_loudly_without_fallback():
+    if fsea.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(fsea.FseaError, match="no CPU fallback"):
+        fsea.Plan(1024)
+
+
+def test_plan_argument_validation_messages():
+    # argument checks run before any device work, so they are testable without a GPU
+    L = fsea.hip_lib()
+    p = ctypes.c_void_p()
+    assert L.fsea_plan_create(ctypes.byref(p), 1000, 1000, 0, 0) == -1
+    assert b"unsupported fft_size" in L.fsea_last_error_string()
+    assert L.fsea_plan_create(ctypes.byref(p), 1024, 12, 0, 0) == -1
+    assert b"multiple of 8" in L.fsea_last_error_string()
+    assert L.fsea_plan_create(ctypes.byref(p), 1024, 1024, 9, 0) == -1
+    assert L.fsea_plan_create(None, 1024, 1024, 0, 0) == -1
+    assert L.fsea_plan_destroy(None) == 0
+
+
+def _libs():
+    ours = nrf.nrf_lib()
+    path = os.path.join(ROOT, "oracle", "_ref", "libnut_ref.so")
+    ref = nrf.bind_nut(ctypes.CDLL(path)) if os.path.exists(path) else None
+    return ours, ref
+
+
+def _drive_nut(L):
+    """A fixed script of nut_buffer calls; returns everything observable."""
+    seen = []
+    u = np.arange(24, dtype=np.uint8) * 9
+    f = np.linspace(-0.4, 0.95, 12)
+    bu = L.nut_buffer_new_u8(12, 2, u.ctypes.data)
+    bf = L.nut_buffer_new_f64(6, 2, f.ctypes.data)
+    bz = L.nut_buffer_new_u8(5, 1, None)
+    for b in (bu, bf, bz):
+        c = b.contents
+        seen.append((c.type, c.length, c.channels, c.size_bytes, nrf.buffer_to_numpy(L, b).tolist()))
+    seen.append([L.nut_buffer_get_f64(bu, i) for i in range(24)])
+    seen.append([L.nut_buffer_get_u8(bf, i) for i in range(12)])
+    L.nut_buffer_set_f64(bu, 3, 0.503)
+    L.nut_buffer_set_u8(bf, 2, 200)
+    cp = L.nut_buffer_copy(bu)
+    rd = L.nut_buffer_reduce(bu, 0.55)
+    rd2 = L.nut_buffer_reduce(bf, 7.0)
+    cl = L.nut_buffer_clip(bu, 4, 3)
+    cl2 = L.nut_buffer_clip(bf, 2, -1)
+    cv = L.nut_buffer_convert(bu, nrf.NUT_BUFFER_F64)
+    cv2 = L.nut_buffer_convert(bf, nrf.NUT_BUFFER_U8)
+    L.nut_buffer_append(cp, rd)
+    five = L.nut_buffer_clip(bu, 7, 5)            # 5 elements x 2 channels, from element 7
+    bz2 = L.nut_buffer_new_u8(5, 2, None)
+    L.nut_buffer_set_data(bz2, five)
+    seen.append(nrf.buffer_to_numpy(L, bz2).tolist())
+    L.nut_buffer_free(five)
+    L.nut_buffer_free(bz2)
+    for b in (cp, rd, rd2, cl, cl2, cv, cv2, bz):
+        c = b.contents
+        seen.append((c.type, c.length, c.channels, c.size_bytes, nrf.buffer_to_numpy(L, b).tolist()))
+    for b in (bu, bf, bz, cp, rd, rd2, cl, cl2, cv, cv2):
+        L.nut_buffer_free(b)
+    return seen
+
+
+def test_nut_buffer_matches_reference_build():
+    ours, ref = _libs()
+    mine = _drive_nut(ours)
+    # self-evident conventions (src/nut.c:121-151)
+    assert mine[3][:3] == [0.0, 9 / 256.0, 18 / 256.0]
+    if ref is None:
+        pytest.skip("oracle/_ref/libnut_ref.so not built (reference absent)")
+    assert mine == _drive_nut(ref)
+
+
+def test_nut_buffer_save_roundtrip(tmp_path):
+    ours, _ = _libs()
+    data = np.arange(64, dtype=np.float64)
+    b = ours.nut_buffer_new_f64(32, 2, data.ctypes.data)
+    path = tmp_path / "buf.raw"
+    ours.nut_buffer_save(b, str(path).encode())
+    ours.nut_buffer_free(b)
+    assert np.array_equal(np.fromfile(path, dtype=np.float64), data)
+
+
+def test_replay_device_flips_and_steps(tmp_path):
+    """nrf_device_new on a 3-block capture: samples = raw ^ 0x80 (src/nrf.c:100-109), paused
+    device steps block by block and wraps (src/nrf.c:153-160, 341-350)."""
+    L = nrf.nrf_lib()
+    raw = synth_iq(11, 3 * nrf.NRF_BUFFER_SIZE_BYTES)
+    path = tmp_path / "cap.raw"
+    raw.tofile(path)
+    dev = L.nrf_device_new(100.9, str(path).encode())
+    try:
+        L.nrf_device_set_paused(dev, 1)
+        import time
+
+        def current():
+            time.sleep(0.06)          # > 2 replay periods of 1/60 s
+            b = L.nrf_device_get_samples_buffer(dev)
+            c = b.contents
+            assert (c.type, c.length, c.channels, c.size_bytes) == (1, 131072, 2, 262144)
+            arr = nrf.buffer_to_numpy(L, b)
+            L.nut_buffer_free(b)
+            return arr
+
+        blocks = raw.reshape(3, -1) ^ np.uint8(0x80)
+        first = current()
+        idx = [i for i in range(3) if np.array_equal(first, blocks[i])]
+        assert len(idx) == 1          # paused on exactly one block
+        for step in range(1, 5):
+            L.nrf_device_step(dev)
+            assert np.array_equal(current(), blocks[(idx[0] + step) % 3])
+        assert L.nrf_device_set_frequency(dev, 433.0) == 433.0
+    finally:
+        L.nrf_device_free(dev)
+
+
+def test_replay_device_missing_file_is_zero_block():
+    L = nrf.nrf_lib()
+    dev = L.nrf_device_new(97.0, b"/nonexistent/capture.raw")
+    try:
+        import time
+        time.sleep(0.05)
+        b = L.nrf_device_get_samples_buffer(dev)
+        arr = nrf.buffer_to_numpy(L, b)
+        L.nut_buffer_free(b)
+        assert np.all(arr == 0x80)    # int8 0 -> offset-binary 128
+    finally:
+        L.nrf_device_free(dev)
