@@ -26,6 +26,9 @@ extern "C" int fsea_kernels_2048(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_4096(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_8192(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_16384(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_var8192a(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_var8192b(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_varsmall(fsea::KernelEntry *out, int cap);
 
 namespace {
 
@@ -55,7 +58,8 @@ const std::vector<fsea::KernelEntry> &registry() {
         std::vector<fsea::KernelEntry> v;
         fsea::KernelEntry tmp[32];
         int (*lists[])(fsea::KernelEntry *, int) = {fsea_kernels_small, fsea_kernels_1024, fsea_kernels_2048,
-                                                    fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384};
+                                                    fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384,
+                                                    fsea_kernels_var8192a, fsea_kernels_var8192b, fsea_kernels_varsmall};
         for (auto fn : lists) {
             int n = fn(tmp, 32);
             for (int i = 0; i < n; ++i) v.push_back(tmp[i]);
@@ -312,7 +316,7 @@ int fsea_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int fli
     if (rc) return rc;
     FSEA_HIP(hipSetDevice(p->device));
     return launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, d_out,
-                  stream ? static_cast<hipStream_t>(stream) : p->stream);
+                  static_cast<hipStream_t>(stream));
 }
 
 int fsea_exec_u8_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip, void *out) {
@@ -372,7 +376,7 @@ int fsea_mean_magnitude_u8_device(fsea_plan *p, const void *d_iq, size_t n_frame
     }
     std::lock_guard<std::mutex> lock(p->mu);
     FSEA_HIP(hipSetDevice(p->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t count = n_frames * (size_t)p->n;
     int rc = ensure(&p->d_aux, &p->d_aux_bytes, count * sizeof(float));
     if (rc) return rc;
@@ -434,7 +438,7 @@ int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes) {
 int fsea_stream_synchronize(fsea_plan *p, void *stream) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
     FSEA_HIP(hipSetDevice(p->device));
-    FSEA_HIP(hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : p->stream));
+    FSEA_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return FSEA_OK;
 }
 
@@ -444,7 +448,7 @@ int fsea_time_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, in
     if (rc) return rc;
     if (reps <= 0 || !avg_ms) return fail(FSEA_EINVAL, "reps must be > 0 and avg_ms non-NULL");
     FSEA_HIP(hipSetDevice(p->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : p->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     FSEA_HIP(hipEventRecord(p->ev0, s));
     for (int i = 0; i < reps; ++i) {
         rc = launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, d_out, s);

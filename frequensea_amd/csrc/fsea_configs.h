@@ -13,3 +13,16 @@
 #define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true
 #define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true
+
+// ---- tuning variants (selected with fsea_plan_create_variant; not the defaults) ----
+#define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true
+#define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true
+#define FSEA_CFG_8192_D 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true
+#define FSEA_CFG_8192_E 8192, 512, 1, 4, 4, 16, 16, 8, 4, false, true
+#define FSEA_CFG_8192_F 8192, 512, 1, 4, 4, 8, 16, 16, 4, false, true
+#define FSEA_CFG_8192_NOTWL 8192, 256, 1, 2, 3, 16, 32, 16, 1, false, true
+#define FSEA_CFG_8192_NOTWR 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, false
+#define FSEA_CFG_1024_B 1024, 64, 4, 4, 3, 16, 16, 4, 1, true, true
+#define FSEA_CFG_1024_C 1024, 64, 4, 4, 3, 4, 16, 16, 1, true, true
+#define FSEA_CFG_1024_D 1024, 32, 4, 2, 2, 32, 32, 1, 1, true, true
+#define FSEA_CFG_4096_B 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true

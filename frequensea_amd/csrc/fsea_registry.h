@@ -32,7 +32,7 @@ struct KernelEntry {
 // Defines the two __global__ entry points (u8 IQ / f32 complex input) of one
 // configuration, with plain C names so that profiles are easy to read, and the
 // launch trampoline + KernelEntry for it.
-#define FSEA_DEFINE_KERNEL(NAME, VARIANT, ...)                                                        \
+#define FSEA_DEFINE_KERNEL(NAME, VARIANT, ...)  /* NAME: C symbol stem; VARIANT: registry key */                                                        \
     using NAME##_cfg = fsea::FftCfg<__VA_ARGS__>;                                                     \
     extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_u8(          \
         fsea::FftArgs a) {                                                                            \

@@ -142,7 +142,7 @@ class Plan:
         return 2 * ((n_frames - 1) * self.hop + self.fft_size) if n_frames else 0
 
     def exec_device(self, d_iq_ptr, n_frames, d_out_ptr, flip=True, stream=0):
-        """Device pointers (ints), asynchronous on `stream` (hipStream_t as int, 0 = plan stream)."""
+        """Device pointers (ints), asynchronous on `stream` (hipStream_t as int, 0 = null stream)."""
         _check(self._L.fsea_exec_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_out_ptr,
                                            stream or None))
 

@@ -94,8 +94,9 @@ int fsea_plan_fft_size(const fsea_plan *plan);
  * flip != 0: bytes are raw HackRF int8 and the kernel applies b ^ 0x80
  * (src/nrf.c:103-106); flip == 0: bytes are already offset-binary (RTL-SDR).
  * d_out: device pointer, n_frames rows of fsea_plan_row_bytes().
- * stream: hipStream_t as void*, or NULL for the plan's own stream.
- * Asynchronous with respect to the host. */
+ * stream: hipStream_t as void*; NULL is HIP's null (default) stream, which is
+ * also what torch.cuda.current_stream().cuda_stream is unless a side stream
+ * is current.  Asynchronous with respect to the host. */
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
                         void *d_out, void *stream);
 
@@ -124,6 +125,7 @@ int fsea_device_alloc(int device, size_t bytes, void **d_ptr);
 int fsea_device_free(int device, void *d_ptr);
 int fsea_copy_to_device(int device, void *d_dst, const void *src, size_t bytes);
 int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes);
+/* Waits for `stream` (NULL = the null stream) on the plan's device. */
 int fsea_stream_synchronize(fsea_plan *plan, void *stream);
 
 /* Measurement helper: runs fsea_exec_u8_device `reps` times back to back on

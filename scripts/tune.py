@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Times every compiled kernel variant on the GPU (HIP events on the launch stream, data set
+larger than the Infinity Cache) and checks a few rows of each against the oracle.
+Usage: python scripts/tune.py [N ...]   -> one line per (N, variant)"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from frequensea_amd import fsea  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+VARIANTS = {
+    8192: ["", "A", "B", "D", "E", "F", "notwl", "notwr"],
+    1024: ["", "B", "C", "D"],
+    4096: ["", "B"],
+    128: [""], 256: [""], 512: [""], 2048: [""], 16384: [""],
+}
+TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch
+
+
+def dev_alloc(nbytes):
+    p = ctypes.c_void_p()
+    fsea._check(fsea.hip_lib().fsea_device_alloc(0, nbytes, ctypes.byref(p)))
+    return p
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [8192, 1024, 4096, 16384, 2048, 512, 256, 128]
+    L = fsea.hip_lib()
+    rng = np.random.default_rng(1)
+    host = rng.integers(-70, 70, 2 * TOTAL_SAMPLES, dtype=np.int8).view(np.uint8)
+    d_in = dev_alloc(host.nbytes)
+    d_out = dev_alloc(4 * TOTAL_SAMPLES)
+    fsea._check(L.fsea_copy_to_device(0, d_in, host.ctypes.data, host.nbytes))
+    for n in sizes:
+        frames = TOTAL_SAMPLES // n
+        want = O.rows(host[: 2 * n * 3], 3, n)
+        for var in VARIANTS.get(n, [""]):
+            try:
+                plan = fsea.Plan(n, variant=var)
+            except fsea.FseaError as e:
+                print("N=%d variant=%-6s unavailable: %s" % (n, var, e))
+                continue
+            plan.time_device(d_in, frames, d_out, 3)                      # warm-up
+            ms = min(plan.time_device(d_in, frames, d_out, 10) for _ in range(3))
+            got = np.empty((3, n), np.float32)
+            fsea._check(L.fsea_copy_to_host(0, got.ctypes.data, d_out, got.nbytes))
+            rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+            gbs = 6.0 * n * frames / (ms * 1e-3) / 1e9
+            grid = plan.grid(frames)
+            print("N=%-5d variant=%-6s %-22s grid=%-5d wg=%-4d lds=%-6d  %8.3f ms  %7.1f Mframes/s  %7.1f GB/s  "
+                  "%.1f%% of 8 TB/s  rel=%.1e %s" % (n, var or "-", plan.kernel_name, grid[0], grid[1], grid[2], ms,
+                                                      frames / ms / 1e3, gbs, gbs / 80.0, rel,
+                                                      "OK" if rel < 1e-6 else "MISMATCH"))
+            plan.close()
+
+
+if __name__ == "__main__":
+    main()

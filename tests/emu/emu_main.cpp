@@ -4,6 +4,7 @@
 #include <barrier>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -52,8 +53,16 @@ static int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsigned gr
 
 // n: transform size; in_kind 0 = u8 IQ, 1 = f32 complex; specialised != 0 selects the
 // compile-time MAG kernel; grid = number of emulated workgroups.
+extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int specialised, const void *in, void *out,
+                               size_t n_frames, size_t hop, int flip, int mode, unsigned grid);
+
 extern "C" int emu_fft(int n, int in_kind, int specialised, const void *in, void *out, size_t n_frames, size_t hop,
                        int flip, int mode, unsigned grid) {
+    return emu_fft_variant(n, "", in_kind, specialised, in, out, n_frames, hop, flip, mode, grid);
+}
+
+extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int specialised, const void *in, void *out,
+                               size_t n_frames, size_t hop, int flip, int mode, unsigned grid) {
     fsea::FftArgs a;
     a.in = in;
     a.out = out;
@@ -62,6 +71,23 @@ extern "C" int emu_fft(int n, int in_kind, int specialised, const void *in, void
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
     const int mt = (specialised && mode == fsea::MODE_MAG && in_kind == fsea::IN_U8) ? 0 : -1;
+    const std::string v = variant ? variant : "";
+    if (!v.empty()) {
+#define EMU_VARIANT(NN, NAME, CFG) \
+    if (n == NN && v == NAME) return dispatch<fsea::FftCfg<CFG>>(in_kind, mt, a, grid);
+        EMU_VARIANT(8192, "A", FSEA_CFG_8192_A)
+        EMU_VARIANT(8192, "B", FSEA_CFG_8192_B)
+        EMU_VARIANT(8192, "D", FSEA_CFG_8192_D)
+        EMU_VARIANT(8192, "E", FSEA_CFG_8192_E)
+        EMU_VARIANT(8192, "F", FSEA_CFG_8192_F)
+        EMU_VARIANT(8192, "notwl", FSEA_CFG_8192_NOTWL)
+        EMU_VARIANT(8192, "notwr", FSEA_CFG_8192_NOTWR)
+        EMU_VARIANT(1024, "B", FSEA_CFG_1024_B)
+        EMU_VARIANT(1024, "C", FSEA_CFG_1024_C)
+        EMU_VARIANT(1024, "D", FSEA_CFG_1024_D)
+        EMU_VARIANT(4096, "B", FSEA_CFG_4096_B)
+        return -2;
+    }
     switch (n) {
     case 128: return dispatch<fsea::FftCfg<FSEA_CFG_128>>(in_kind, mt, a, grid);
     case 256: return dispatch<fsea::FftCfg<FSEA_CFG_256>>(in_kind, mt, a, grid);

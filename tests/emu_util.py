@@ -27,15 +27,18 @@ def emu_lib():
         L = ctypes.CDLL(out)
         L.emu_fft.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                               ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+        L.emu_fft_variant.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_uint]
         _EMU = L
     return _EMU
 
 
-def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0):
+def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0, variant=""):
     hop = n if hop is None else hop
     src = np.ascontiguousarray(iq)
     out = np.zeros((n_frames, n), dtype=OUT_DTYPE[mode])
-    rc = emu_lib().emu_fft(n, in_kind, int(specialised), src.ctypes.data, out.ctypes.data, n_frames, hop,
-                           int(bool(flip)), mode, grid)
-    assert rc == 0
+    rc = emu_lib().emu_fft_variant(n, variant.encode(), in_kind, int(specialised), src.ctypes.data,
+                                   out.ctypes.data, n_frames, hop, int(bool(flip)), mode, grid)
+    assert rc == 0, "emu_fft_variant(%d, %r) = %d" % (n, variant, rc)
     return out

@@ -99,3 +99,15 @@ def test_edge_inputs():
     parity.check_mode(got, ext, n, 1, n, True, 0)
     # zero frames: nothing is written
     assert emu_rows(z, n, 0).shape == (0, n)
+
+
+@pytest.mark.parametrize("n,variant", [(8192, "A"), (8192, "B"), (8192, "D"), (8192, "E"), (8192, "F"),
+                                       (8192, "notwl"), (8192, "notwr"), (1024, "B"), (1024, "C"), (1024, "D"),
+                                       (4096, "B")])
+def test_tuning_variants(n, variant):
+    """Every kernel variant compiled into libfsea_hip.so (fsea_plan_create_variant) stays correct."""
+    nf = 9 if n <= 1024 else 3
+    iq = synth_iq(n + len(variant), 2 * nf * n)
+    for mode in (0, 1, 3):
+        got = emu_rows(iq, n, nf, mode=mode, grid=2, specialised=(mode == 0), variant=variant)
+        parity.check_mode(got, iq, n, nf, n, True, mode)
