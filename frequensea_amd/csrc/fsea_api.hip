@@ -147,7 +147,7 @@ struct fsea_plan {
     int device = 0;
     const fsea::KernelEntry *entry = nullptr;
     hipStream_t stream = nullptr;
-    float2 *d_tw = nullptr;       // passes 1..np-1 concatenated
+    fsea::cf *d_tw = nullptr;      // passes 1..np-1 concatenated
     size_t tw_off[4] = {0, 0, 0, 0};
     int num_cu = 0;
     int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0;
@@ -260,9 +260,9 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
 
     std::vector<fsea::TwPair> tw;
     fsea::build_twiddles(e->np, e->radix, tw, p->tw_off);
-    static_assert(sizeof(fsea::TwPair) == sizeof(float2), "twiddle layout");
-    hipError_t he = hipMalloc(reinterpret_cast<void **>(&p->d_tw), tw.size() * sizeof(float2));
-    if (he == hipSuccess) he = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+    static_assert(sizeof(fsea::TwPair) == sizeof(fsea::cf), "twiddle layout");
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&p->d_tw), tw.size() * sizeof(fsea::cf));
+    if (he == hipSuccess) he = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(fsea::cf), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_acc), sizeof(double));
     if (he == hipSuccess) he = hipEventCreate(&p->ev0);

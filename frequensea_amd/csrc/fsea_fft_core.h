@@ -18,6 +18,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <fsea_pk_asm.h>  // cf (packed complex), pk_cmul
+
 namespace fsea {
 
 // ---------------------------------------------------------------------------
@@ -67,49 +69,46 @@ __host__ __device__ constexpr float cos64(int m) {
 __host__ __device__ constexpr float sin64(int m) { return cos64((m - 16) & 63); }
 
 // ---------------------------------------------------------------------------
-// radix-2 butterfly with the constant twiddle w = exp(-2 pi i k / L).
-// (a, b) <- (a + w b, a - w b).  L and k are compile-time after unrolling.
-// The general case uses the FMA form: plus = a + w b (4 fma), minus = 2a - plus
-// (2 fma) -- 6 VALU instead of 8.
+// Packed complex arithmetic.  A complex value is one even-aligned VGPR pair
+// (cf = 2 x f32) and every butterfly is written so that it selects gfx950's
+// packed-f32 VALU ops (v_pk_add/mul/fma_f32: two flops per lane per issue; the
+// scalar forms issue at about the same rate, scripts/ubench/valu_rate.hip), with
+// swizzles and full-vector negations folded into op_sel / neg modifiers and the
+// constant twiddles living in SGPR pairs.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void bfly_const(int L, int k, float2 &a, float2 &b) {
+__device__ __forceinline__ cf cf_swap(cf b) { return __builtin_shufflevector(b, b, 1, 0); }
+__device__ __forceinline__ cf cf_fma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
+
+// radix-2 butterfly with the constant twiddle w = exp(-2 pi i k / L) = (wr, wi):
+// (a, b) <- (a + w b, a - w b).  L and k are compile-time after unrolling.
+//   plus  = a + wr * b + (-wi, wi) * swap(b)      2 pk_fma (1 when wr == 0)
+//   minus = 2 a - plus                            1 pk_fma
+__device__ __forceinline__ void bfly_const(int L, int k, cf &a, cf &b) {
     if (k == 0) {
-        const float2 t = b;
-        b = make_float2(a.x - t.x, a.y - t.y);
-        a = make_float2(a.x + t.x, a.y + t.y);
+        const cf t = b;
+        b = a - t;
+        a = a + t;
     } else if (4 * k == L) {  // w = -i : w b = (b.y, -b.x)
-        const float2 t = make_float2(b.y, -b.x);
-        b = make_float2(a.x - t.x, a.y - t.y);
-        a = make_float2(a.x + t.x, a.y + t.y);
-    } else if (8 * k == L) {  // w = (1 - i)/sqrt2 : w b = h (b.x + b.y, b.y - b.x)
-        const float h = 0.70710678118654752f;
-        const float s = b.x + b.y, d = b.y - b.x;
-        b = make_float2(__builtin_fmaf(-h, s, a.x), __builtin_fmaf(-h, d, a.y));
-        a = make_float2(__builtin_fmaf(h, s, a.x), __builtin_fmaf(h, d, a.y));
-    } else if (8 * k == 3 * L) {  // w = (-1 - i)/sqrt2 : w b = h (b.y - b.x, -(b.x + b.y))
-        const float h = 0.70710678118654752f;
-        const float s = b.y - b.x, d = b.x + b.y;
-        b = make_float2(__builtin_fmaf(-h, s, a.x), __builtin_fmaf(h, d, a.y));
-        a = make_float2(__builtin_fmaf(h, s, a.x), __builtin_fmaf(-h, d, a.y));
+        const cf sb = cf_swap(b);
+        b = cf_fma(sb, cf{-1.0f, 1.0f}, a);
+        a = cf_fma(sb, cf{1.0f, -1.0f}, a);
     } else {
         const int m = k * (64 / L);
         const float wr = cos64(m), wi = -sin64(m);
-        float pr = __builtin_fmaf(wr, b.x, a.x);
-        pr = __builtin_fmaf(-wi, b.y, pr);
-        float pi = __builtin_fmaf(wr, b.y, a.y);
-        pi = __builtin_fmaf(wi, b.x, pi);
-        b = make_float2(__builtin_fmaf(2.0f, a.x, -pr), __builtin_fmaf(2.0f, a.y, -pi));
-        a = make_float2(pr, pi);
+        cf plus = cf_fma(b, cf{wr, wr}, a);
+        plus = cf_fma(cf_swap(b), cf{-wi, wi}, plus);
+        b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
+        a = plus;
     }
 }
 
 // R-point DFT (forward, -1 exponent) over x[0], x[S], ..., x[(R-1)S];
 // natural order in and out.  Bit reversal is register renaming only.
 template <int R, int S>
-__device__ __forceinline__ void dft_regs(float2 *x) {
+__device__ __forceinline__ void dft_regs(cf *x) {
     static_assert(R >= 2 && R <= 64 && (R & (R - 1)) == 0, "radix must be 2..64");
     constexpr int BITS = ilog2c(R);
-    float2 y[R];
+    cf y[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) y[bitrev_c(i, BITS)] = x[i * S];
 #pragma unroll
@@ -124,10 +123,6 @@ __device__ __forceinline__ void dft_regs(float2 *x) {
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
-}
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
-    return make_float2(__builtin_fmaf(-a.y, w.y, a.x * w.x), __builtin_fmaf(a.y, w.x, a.x * w.y));
 }
 
 // ---------------------------------------------------------------------------
@@ -159,7 +154,7 @@ struct FftCfg {
     static constexpr int C(int i) { return P / R(i); }
     static constexpr int Ns(int i) { return i == 0 ? 1 : Ns(i - 1) * R(i - 1); }
     static constexpr int tw_len(int i) { return i == 0 ? 0 : (R(i) - 1) * Ns(i); }
-    // LDS (in float2 units): FPW padded frames, then the middle-pass tables.
+    // LDS (in complex = 8-byte units): FPW padded frames, then the middle-pass tables.
     static constexpr int pad(int idx) { return lds_pad<N_ / T_>(idx); }
     static constexpr int LDS_FRAME = N_ + 2 * T_;
     static constexpr int lds_tw_off(int i) {
@@ -178,49 +173,49 @@ struct FftArgs {
     size_t hop;           // samples between frame starts
     uint32_t xormask;     // u8 input: 0 when flip (raw int8), 0x80808080 otherwise
     int mode;             // MODE_*
-    const float2 *tw[4];  // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
+    const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
 };
 
 // ---------------------------------------------------------------------------
 // small typed memory helpers
 // ---------------------------------------------------------------------------
 template <int C>
-__device__ __forceinline__ void ld_c(const float2 *p, float2 *dst) {
+__device__ __forceinline__ void ld_c(const cf *p, cf *dst) {
     if constexpr (C == 1) {
         dst[0] = *p;
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 2) {
-            const float4 q = *reinterpret_cast<const float4 *>(p + c);
-            dst[c] = make_float2(q.x, q.y);
-            dst[c + 1] = make_float2(q.z, q.w);
+            const cf2 q = *reinterpret_cast<const cf2 *>(p + c);
+            dst[c] = cf{q[0], q[1]};
+            dst[c + 1] = cf{q[2], q[3]};
         }
     }
 }
 
 template <int C>
-__device__ __forceinline__ void st_c(float2 *p, const float2 *src) {
+__device__ __forceinline__ void st_c(cf *p, const cf *src) {
     if constexpr (C == 1) {
         *p = src[0];
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 2) {
-            *reinterpret_cast<float4 *>(p + c) = make_float4(src[c].x, src[c].y, src[c + 1].x, src[c + 1].y);
+            *reinterpret_cast<cf2 *>(p + c) = cf2{src[c][0], src[c][1], src[c + 1][0], src[c + 1][1]};
         }
     }
 }
 
-// C consecutive output elements of type E (float, uint8_t or float2) at p.
+// C consecutive output elements (float, uint8_t or complex) at p.
 template <int C>
 __device__ __forceinline__ void st_out(float *p, const float *v) {
     if constexpr (C == 1) {
         p[0] = v[0];
     } else if constexpr (C == 2) {
-        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+        *reinterpret_cast<cf *>(p) = cf{v[0], v[1]};
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
-            *reinterpret_cast<float4 *>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+            *reinterpret_cast<cf2 *>(p + c) = cf2{v[c], v[c + 1], v[c + 2], v[c + 3]};
         }
     }
 }
@@ -241,7 +236,7 @@ __device__ __forceinline__ void st_out(uint8_t *p, const uint8_t *v) {
 }
 
 template <int C>
-__device__ __forceinline__ void st_out(float2 *p, const float2 *v) {
+__device__ __forceinline__ void st_out(cf *p, const cf *v) {
     st_c<C>(p, v);
 }
 
@@ -257,28 +252,25 @@ struct RawRow<IN_U8, 4> { uint2 w; };
 template <>
 struct RawRow<IN_U8, 8> { uint4 w; };
 template <int C>
-struct RawRow<IN_F32, C> { float2 w[C]; };
+struct RawRow<IN_F32, C> { cf w[C]; };
 
 __device__ __forceinline__ float s8f(uint32_t w, int byte) {
     return (float)(int8_t)(uint8_t)(w >> (8 * byte));
 }
 
 // Convert one raw row to C complex samples in integer units (u - 128); the
-// 1/256 scale is applied by the epilogue.  (-1)^n is applied here as a sign
-// on odd columns (row strides are even), which the compiler folds into the
-// first butterflies as operand negation.
+// 1/256 scale is applied later.  (-1)^n is applied here as a negation of odd
+// columns (row strides are even), which the compiler folds into the neg
+// modifiers of the first butterflies.
 template <int IN, int C>
-__device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t xormask, int j0, float2 *dst) {
+__device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t xormask, int j0, cf *dst) {
     if constexpr (IN == IN_F32) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float sg = ((j0 + c) & 1) ? -1.0f : 1.0f;
-            dst[c] = make_float2(sg * raw.w[c].x, sg * raw.w[c].y);
-        }
+        for (int c = 0; c < C; ++c) dst[c] = ((j0 + c) & 1) ? -raw.w[c] : raw.w[c];
     } else if constexpr (C == 1) {
         const uint32_t w = (uint32_t)raw.w ^ xormask;
-        const float sg = (j0 & 1) ? -1.0f : 1.0f;
-        dst[0] = make_float2(sg * s8f(w, 0), sg * s8f(w, 1));
+        const cf z = cf{s8f(w, 0), s8f(w, 1)};
+        dst[0] = (j0 & 1) ? -z : z;
     } else {
         uint32_t words[C / 2];
         if constexpr (C == 2) {
@@ -295,8 +287,8 @@ __device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t x
 #pragma unroll
         for (int q = 0; q < C / 2; ++q) {
             const uint32_t w = words[q] ^ xormask;
-            dst[2 * q] = make_float2(s8f(w, 0), s8f(w, 1));        // even column: +
-            dst[2 * q + 1] = make_float2(-s8f(w, 2), -s8f(w, 3));  // odd column: -
+            dst[2 * q] = cf{s8f(w, 0), s8f(w, 1)};         // even column: +
+            dst[2 * q + 1] = -cf{s8f(w, 2), s8f(w, 3)};    // odd column: -
         }
     }
 }
@@ -313,6 +305,11 @@ struct FftKernel {
     static constexpr int R0 = Cfg::R(0), C0 = Cfg::C(0);
     static constexpr int RL = Cfg::R(LAST), CL = Cfg::C(LAST), NsL = Cfg::Ns(LAST);
     static constexpr bool ONE_WAVE = (Cfg::WG <= 64) || (T <= 64 && (64 % T) == 0);
+    // u8 input is transformed in integer units; the 1/256 of x = u8/256.0 is folded
+    // into the register-resident last-pass twiddles (and one multiply of the
+    // untwiddled row), or applied by the epilogue when those are not in registers.
+    static constexpr float SC = (IN == IN_U8) ? (1.0f / 256.0f) : 1.0f;
+    static constexpr bool PRESCALED = Cfg::TWR && (IN == IN_U8);
     using Raw = RawRow<IN, C0>;
 
     // Frames of one workgroup exchange through LDS.  When a frame lives inside
@@ -341,7 +338,7 @@ struct FftKernel {
                 if constexpr (C0 == 8) raw[r].w = *reinterpret_cast<const uint4 *>(p);
             }
         } else {
-            const float2 *base = static_cast<const float2 *>(a.in) + frame * a.hop + (size_t)(C0 * t);
+            const cf *base = static_cast<const cf *>(a.in) + frame * a.hop + (size_t)(C0 * t);
 #pragma unroll
             for (int r = 0; r < R0; ++r) ld_c<C0>(base + r * STRIDE, raw[r].w);
         }
@@ -349,12 +346,12 @@ struct FftKernel {
 
     // twiddle multiply for pass I (I >= 1): v[r*C + c] *= W^{r k}, k = (C t + c) % Ns
     template <int I>
-    static __device__ __forceinline__ void apply_twiddles(float2 *v, const float2 *tw, int t) {
+    static __device__ __forceinline__ void apply_twiddles(cf *v, const cf *tw, int t) {
         constexpr int R = Cfg::R(I), C = Cfg::C(I), Ns = Cfg::Ns(I);
         const int k0 = (C * t) % Ns;
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-            float2 w[C];
+            cf w[C];
             if constexpr (Ns % C == 0) {
                 ld_c<C>(tw + (r - 1) * Ns + k0, w);
             } else {
@@ -362,7 +359,7 @@ struct FftKernel {
                 for (int c = 0; c < C; ++c) w[c] = tw[(r - 1) * Ns + (C * t + c) % Ns];
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) v[r * C + c] = cmul(v[r * C + c], w[c]);
+            for (int c = 0; c < C; ++c) v[r * C + c] = pk_cmul(v[r * C + c], w[c]);
         }
     }
 
@@ -371,17 +368,17 @@ struct FftKernel {
     // on the thread part only; written out so that the r-dependent part becomes the
     // immediate offset of the ds_* instruction.
     template <int I>
-    static __device__ __forceinline__ void lds_write(float2 *lds, const float2 *v, int t) {
+    static __device__ __forceinline__ void lds_write(cf *lds, const cf *v, int t) {
         constexpr int R = Cfg::R(I), C = Cfg::C(I), Ns = Cfg::Ns(I);
         if constexpr (Ns == 1 && (R % 2) == 0) {
             // column c owns R contiguous outputs at (C t + c) R: the thread's P
             // outputs are the run [P t, P t + P), i.e. pad adds exactly 2 t.
-            float2 *base = lds + (unsigned)((P + 2) * t);
+            cf *base = lds + (unsigned)((P + 2) * t);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
 #pragma unroll
                 for (int r = 0; r < R; r += 2) {
-                    const float2 pr[2] = {v[r * C + c], v[(r + 1) * C + c]};
+                    const cf pr[2] = {v[r * C + c], v[(r + 1) * C + c]};
                     st_c<2>(base + (c * R + r), pr);
                 }
             }
@@ -389,7 +386,7 @@ struct FftKernel {
             const unsigned j = (unsigned)(C * t);
             const unsigned j0 = (j / Ns) * (Ns * R) + (j % Ns);
             if constexpr (Ns % P == 0) {
-                float2 *base = lds + Cfg::pad(j0);
+                cf *base = lds + Cfg::pad(j0);
 #pragma unroll
                 for (int r = 0; r < R; ++r) st_c<C>(base + r * (Ns + 2 * (Ns / P)), v + r * C);
             } else {
@@ -398,7 +395,7 @@ struct FftKernel {
                 static_assert(P % Ns == 0 && R % Q == 0, "pad addressing needs Ns | P and (P/Ns) | R");
 #pragma unroll
                 for (int b = 0; b < Q; ++b) {
-                    float2 *base = lds + Cfg::pad(j0 + b * Ns);
+                    cf *base = lds + Cfg::pad(j0 + b * Ns);
 #pragma unroll
                     for (int rq = 0; rq < R / Q; ++rq) st_c<C>(base + rq * (P + 2), v + (rq * Q + b) * C);
                 }
@@ -415,11 +412,11 @@ struct FftKernel {
     }
 
     template <int I>
-    static __device__ __forceinline__ void lds_read(const float2 *lds, float2 *v, int t) {
+    static __device__ __forceinline__ void lds_read(const cf *lds, cf *v, int t) {
         constexpr int R = Cfg::R(I), C = Cfg::C(I);
         constexpr int STRIDE = N / R;
         if constexpr (STRIDE % P == 0) {
-            const float2 *base = lds + Cfg::pad(C * t);
+            const cf *base = lds + Cfg::pad(C * t);
 #pragma unroll
             for (int r = 0; r < R; ++r) ld_c<C>(base + r * (STRIDE + 2 * (STRIDE / P)), v + r * C);
         } else {
@@ -430,13 +427,12 @@ struct FftKernel {
 
     // middle pass I (1 <= I < LAST): read, twiddle, DFT, write back
     template <int I>
-    static __device__ __forceinline__ void middle_pass(float2 *lds, const float2 *lds_all, float2 *v,
-                                                       const FftArgs &a, int t) {
+    static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t) {
         if constexpr (I < LAST) {
             constexpr int R = Cfg::R(I), C = Cfg::C(I);
             lds_read<I>(lds, v, t);
             frame_sync();  // everyone has read before anyone overwrites
-            const float2 *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
+            const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
             apply_twiddles<I>(v, tw, t);
 #pragma unroll
             for (int c = 0; c < C; ++c) dft_regs<R, C>(v + c);
@@ -447,28 +443,28 @@ struct FftKernel {
     }
 
     // fused epilogue for the row held as v[r*CL + c] = bin CL t + c + r NsL
-    static __device__ __forceinline__ void epilogue(const FftArgs &a, size_t frame, float2 *v, int t) {
-        constexpr float SC = (IN == IN_U8) ? (1.0f / 256.0f) : 1.0f;  // input scale u8/256
-        constexpr float SC2 = SC * SC;
+    static __device__ __forceinline__ void epilogue(const FftArgs &a, size_t frame, cf *v, int t) {
+        constexpr float SE = PRESCALED ? 1.0f : SC;  // scale still to apply to re / im
+        constexpr float SE2 = SE * SE;
         const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
         const bool patched = (mode == MODE_MAG) || (mode == MODE_DB5_U8_DCFIX);
         // Offset-binary input carries a DC term 0.5 per component, which the
         // (-1)^n centring moves to bin N/2 exactly: 0.5 N (1 + i).  The kernel
         // transforms (u - 128) instead and restores that bin analytically in
-        // the modes that keep it (in integer units: 128 N).
+        // the modes that keep it.
         if (IN == IN_U8 && !patched && t == 0) {
-            v[(RL / 2) * CL].x += 128.0f * (float)N;
-            v[(RL / 2) * CL].y += 128.0f * (float)N;
+            const float dc = (PRESCALED ? 0.5f : 128.0f) * (float)N;
+            v[(RL / 2) * CL] += cf{dc, dc};
         }
         const size_t row = frame * (size_t)N;
         const int k0 = CL * t;
         if (mode == MODE_COMPLEX) {
-            float2 *o = static_cast<float2 *>(a.out) + row + k0;
+            cf *o = static_cast<cf *>(a.out) + row + k0;
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
-                float2 z[CL];
+                cf z[CL];
 #pragma unroll
-                for (int c = 0; c < CL; ++c) z[c] = make_float2(v[r * CL + c].x * SC, v[r * CL + c].y * SC);
+                for (int c = 0; c < CL; ++c) z[c] = v[r * CL + c] * cf{SE, SE};
                 st_out<CL>(o + r * NsL, z);
             }
         } else if (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) {
@@ -480,8 +476,9 @@ struct FftKernel {
                 uint8_t px[CL];
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
-                    const float2 z = v[r * CL + c];
-                    const float p = __builtin_fmaf(z.x, z.x, z.y * z.y) * SC2;
+                    const cf z = v[r * CL + c];
+                    float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
+                    if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
                     const float d = kdb * __builtin_amdgcn_logf(p + 1.0e-20f);
                     int q = (int)d;  // truncation toward zero, as the C cast in the reference
                     q = q < 0 ? 0 : (q > 255 ? 255 : q);
@@ -502,8 +499,9 @@ struct FftKernel {
                 float m[CL];
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
-                    const float2 z = v[r * CL + c];
-                    const float p = __builtin_fmaf(z.x, z.x, z.y * z.y) * SC2;
+                    const cf z = v[r * CL + c];
+                    float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
+                    if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
                     if (mode == MODE_DB_F32) {
                         m[c] = (10.0f * 0.30102999566398120f) * __builtin_amdgcn_logf(p + 1.0e-20f);
                     } else {
@@ -521,16 +519,16 @@ struct FftKernel {
         }
     }
 
-    static __device__ __forceinline__ void run(const FftArgs &a, float2 *lds_all) {
+    static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
         const int tid = threadIdx.x;
         const int slot = tid / T;
         const int t = tid % T;
-        float2 *lds = lds_all + slot * Cfg::LDS_FRAME;
+        cf *lds = lds_all + slot * Cfg::LDS_FRAME;
 
         // middle-pass twiddle tables -> LDS, once per workgroup
         if constexpr (Cfg::TWL && NP > 2) {
             constexpr int TOT = Cfg::LDS_TOTAL - FPW * Cfg::LDS_FRAME;
-            float2 *dst = lds_all + FPW * Cfg::LDS_FRAME;
+            cf *dst = lds_all + FPW * Cfg::LDS_FRAME;
             for (int i = tid; i < TOT; i += Cfg::WG) {
                 // tables of passes 1..LAST-1 are contiguous in the global image too
                 dst[i] = a.tw[1][i];
@@ -539,10 +537,14 @@ struct FftKernel {
         }
 
         // last-pass twiddles in registers for the lifetime of the workgroup
-        float2 twl[Cfg::TWR ? (RL - 1) * CL : 1];
+        cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
         if constexpr (Cfg::TWR) {
 #pragma unroll
             for (int r = 1; r < RL; ++r) ld_c<CL>(a.tw[LAST] + (r - 1) * NsL + CL * t, twl + (r - 1) * CL);
+            if constexpr (PRESCALED) {
+#pragma unroll
+                for (int i = 0; i < (RL - 1) * CL; ++i) twl[i] = twl[i] * cf{SC, SC};
+            }
         }
 
         // XCD-aware unit mapping: workgroup b runs on XCD b % 8; give each XCD a
@@ -571,13 +573,13 @@ struct FftKernel {
             const size_t frame_n = un * FPW + slot;
             const bool live_n = (un < u_end) && (frame_n < a.n_frames);
 
-            float2 v[P];
+            cf v[P];
             if (live) {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
             } else {
 #pragma unroll
-                for (int i = 0; i < P; ++i) v[i] = make_float2(0.f, 0.f);
+                for (int i = 0; i < P; ++i) v[i] = cf{0.f, 0.f};
             }
             // prefetch: the next frame's bytes are requested as soon as this frame's
             // are converted and stay in flight during the whole transform
@@ -592,10 +594,14 @@ struct FftKernel {
             lds_read<LAST>(lds, v, t);
             frame_sync();  // the buffer is free for the next frame's pass 0
             if constexpr (Cfg::TWR) {
+                if constexpr (PRESCALED) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) v[c] = v[c] * cf{SC, SC};  // row 0 has no twiddle
+                }
 #pragma unroll
                 for (int r = 1; r < RL; ++r) {
 #pragma unroll
-                    for (int c = 0; c < CL; ++c) v[r * CL + c] = cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
+                    for (int c = 0; c < CL; ++c) v[r * CL + c] = pk_cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
                 }
             } else {
                 apply_twiddles<LAST>(v, a.tw[LAST], t);

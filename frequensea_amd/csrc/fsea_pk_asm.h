@@ -1,0 +1,25 @@
+// fsea_pk_asm.h -- the packed complex type and the one operation the compiler
+// cannot select optimally from C++: a complex multiply by a run-time twiddle.
+// hipcc folds swizzles and whole-vector negations into op_sel / neg modifiers
+// of v_pk_* instructions, but not the single-lane negation a complex product
+// needs, so that product is written as two VOP3P instructions by hand:
+//   t   = a * (w.x, w.x)                              v_pk_mul_f32, op_sel broadcast of w.x
+//   t.x = -a.y * w.y + t.x ; t.y = a.x * w.y + t.y    v_pk_fma_f32, swapped a, broadcast w.y,
+//                                                     neg_lo on the w operand
+// Register-only, non-volatile asm: the scheduler may move it freely; plain VALU
+// RAW dependencies are interlocked in hardware, no wait states are needed.
+#pragma once
+
+namespace fsea {
+
+typedef float cf __attribute__((vector_size(8)));    // (re, im) in an aligned VGPR pair
+typedef float cf2 __attribute__((vector_size(16)));  // two of them, for 16-byte memory ops
+
+__device__ __forceinline__ cf pk_cmul(cf a, cf w) {
+    cf t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(a), "v"(w));
+    return t;
+}
+
+}  // namespace fsea

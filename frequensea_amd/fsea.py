@@ -35,7 +35,8 @@ class FseaError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfsea_hip.so")
+    # FSEA_HIP_LIB: tuning hook to load an alternative build of the same library
+    return os.environ.get("FSEA_HIP_LIB") or os.path.join(_HERE, "libfsea_hip.so")
 
 
 def build(jobs=8):

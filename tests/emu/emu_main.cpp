@@ -22,10 +22,10 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
     size_t off[4];
     const int radix[4] = {Cfg::R(0), Cfg::R(1), Cfg::R(2), Cfg::R(3)};
     fsea::build_twiddles(Cfg::NP, radix, tw, off);
-    for (int i = 0; i < 4; ++i) a.tw[i] = reinterpret_cast<const float2 *>(tw.data()) + off[i];
+    for (int i = 0; i < 4; ++i) a.tw[i] = reinterpret_cast<const fsea::cf *>(tw.data()) + off[i];
     for (unsigned b = 0; b < grid; ++b) {
-        std::vector<float2> lds_store(Cfg::LDS_TOTAL + 2);
-        float2 *lds = lds_store.data();
+        std::vector<fsea::cf> lds_store(Cfg::LDS_TOTAL + 2);
+        fsea::cf *lds = lds_store.data();
         if (reinterpret_cast<uintptr_t>(lds) & 15) lds += 1;  // 16-byte alignment as on the device
         std::barrier<> bar(Cfg::WG);
         std::vector<std::thread> th;

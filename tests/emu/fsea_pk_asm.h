@@ -1,0 +1,16 @@
+// TEST-ONLY stand-in for frequensea_amd/csrc/fsea_pk_asm.h (found first on the emulation
+// build's include path): same types, the complex multiply written in plain C++.
+#pragma once
+
+namespace fsea {
+
+typedef float cf __attribute__((vector_size(8)));
+typedef float cf2 __attribute__((vector_size(16)));
+
+static inline cf pk_cmul(cf a, cf w) {
+    cf t = cf{a[0] * w[0], a[1] * w[0]};
+    t = cf{fmaf(-a[1], w[1], t[0]), fmaf(a[0], w[1], t[1])};
+    return t;
+}
+
+}  // namespace fsea

@@ -30,5 +30,19 @@ void emu_syncthreads();
 #define __syncthreads() emu_syncthreads()
 #define __builtin_amdgcn_wave_barrier() emu_syncthreads()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+// clang vector builtins used by the packed-math code, for g++ vector_size types
+template <class V>
+static inline V emu_elementwise_fma(V a, V b, V c) {
+    V r;
+    for (unsigned i = 0; i < sizeof(V) / sizeof(float); ++i) r[i] = fmaf(a[i], b[i], c[i]);
+    return r;
+}
+#define __builtin_elementwise_fma(a, b, c) emu_elementwise_fma(a, b, c)
+template <class V>
+static inline V emu_shuffle2(V a, V b, int i, int j) {
+    const float src[4] = {a[0], a[1], b[0], b[1]};
+    return V{src[i], src[j]};
+}
+#define __builtin_shufflevector(a, b, i, j) emu_shuffle2(a, b, i, j)
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_logf(x) log2f(x)
