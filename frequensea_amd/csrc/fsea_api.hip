@@ -29,6 +29,8 @@ extern "C" int fsea_kernels_16384(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_var8192a(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_var8192b(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_varsmall(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_varmid(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_ablate(fsea::KernelEntry *out, int cap);
 
 namespace {
 
@@ -59,7 +61,8 @@ const std::vector<fsea::KernelEntry> &registry() {
         fsea::KernelEntry tmp[32];
         int (*lists[])(fsea::KernelEntry *, int) = {fsea_kernels_small, fsea_kernels_1024, fsea_kernels_2048,
                                                     fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384,
-                                                    fsea_kernels_var8192a, fsea_kernels_var8192b, fsea_kernels_varsmall};
+                                                    fsea_kernels_var8192a, fsea_kernels_var8192b, fsea_kernels_varsmall,
+                                                    fsea_kernels_varmid, fsea_kernels_ablate};
         for (auto fn : lists) {
             int n = fn(tmp, 32);
             for (int i = 0; i < n; ++i) v.push_back(tmp[i]);

@@ -11,12 +11,12 @@
 #define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true
 // multi-wave frames
 #define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true
-#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
+#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true
 
 // ---- tuning variants (selected with fsea_plan_create_variant; not the defaults) ----
 #define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true
-#define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true
+#define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
 #define FSEA_CFG_8192_D 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true
 #define FSEA_CFG_8192_E 8192, 512, 1, 4, 4, 16, 16, 8, 4, false, true
 #define FSEA_CFG_8192_F 8192, 512, 1, 4, 4, 8, 16, 16, 4, false, true
@@ -26,3 +26,14 @@
 #define FSEA_CFG_1024_C 1024, 64, 4, 4, 3, 4, 16, 16, 1, true, true
 #define FSEA_CFG_1024_D 1024, 32, 4, 2, 2, 32, 32, 1, 1, true, true
 #define FSEA_CFG_4096_B 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true
+#define FSEA_CFG_4096_C 4096, 128, 2, 2, 3, 16, 8, 32, 1, true, true
+#define FSEA_CFG_4096_D 4096, 128, 2, 2, 3, 8, 16, 32, 1, true, true
+#define FSEA_CFG_16384_B 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true
+#define FSEA_CFG_2048_B 2048, 64, 4, 2, 3, 8, 8, 32, 1, true, true
+#define FSEA_CFG_2048_C 2048, 64, 4, 2, 3, 4, 16, 32, 1, true, true
+// measurement-only ablations of 8192 "B" (results are wrong by design; never the default)
+#define FSEA_CFG_8192_B_NOST 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 1
+#define FSEA_CFG_8192_B_NOLDS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 2
+#define FSEA_CFG_8192_B_NOFLOP 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4
+#define FSEA_CFG_8192_B_IO 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6
+#define FSEA_CFG_8192_B_VALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 3

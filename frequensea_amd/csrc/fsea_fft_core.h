@@ -104,8 +104,9 @@ __device__ __forceinline__ void bfly_const(int L, int k, cf &a, cf &b) {
 
 // R-point DFT (forward, -1 exponent) over x[0], x[S], ..., x[(R-1)S];
 // natural order in and out.  Bit reversal is register renaming only.
-template <int R, int S>
+template <int R, int S, bool SKIP = false>
 __device__ __forceinline__ void dft_regs(cf *x) {
+    if constexpr (SKIP) return;
     static_assert(R >= 2 && R <= 64 && (R & (R - 1)) == 0, "radix must be 2..64");
     constexpr int BITS = ilog2c(R);
     cf y[R];
@@ -143,8 +144,11 @@ enum : int { IN_U8 = 0, IN_F32 = 1 };
 // live in LDS (else they are fetched from the global table every frame);
 // TWR: the last pass keeps its twiddles in registers across the frame loop.
 template <int N_, int T_, int FPW_, int WPE_, int NP_, int R0_, int R1_, int R2_ = 1, int R3_ = 1,
-          bool TWL_ = true, bool TWR_ = true>
+          bool TWL_ = true, bool TWR_ = true, int ABL_ = 0>
 struct FftCfg {
+    // ABL: measurement-only ablations (tuning variants, results are wrong by design):
+    // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
+    static constexpr int ABL = ABL_;
     static constexpr int N = N_, T = T_, FPW = FPW_, NP = NP_;
     static constexpr int WPE = WPE_;  // waves per SIMD the register budget must allow
     static constexpr int P = N_ / T_;
@@ -316,7 +320,9 @@ struct FftKernel {
     // a single wavefront no s_barrier is needed: LDS operations of one wave
     // execute in order.
     static __device__ __forceinline__ void frame_sync() {
-        if constexpr (ONE_WAVE) {
+        if constexpr (Cfg::ABL & 2) {
+            return;
+        } else if constexpr (ONE_WAVE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -359,7 +365,10 @@ struct FftKernel {
                 for (int c = 0; c < C; ++c) w[c] = tw[(r - 1) * Ns + (C * t + c) % Ns];
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) v[r * C + c] = pk_cmul(v[r * C + c], w[c]);
+            for (int c = 0; c < C; ++c) {
+                if constexpr (Cfg::ABL & 4) v[r * C + c] += w[c];
+                else v[r * C + c] = pk_cmul(v[r * C + c], w[c]);
+            }
         }
     }
 
@@ -370,7 +379,9 @@ struct FftKernel {
     template <int I>
     static __device__ __forceinline__ void lds_write(cf *lds, const cf *v, int t) {
         constexpr int R = Cfg::R(I), C = Cfg::C(I), Ns = Cfg::Ns(I);
-        if constexpr (Ns == 1 && (R % 2) == 0) {
+        if constexpr (Cfg::ABL & 2) {
+            return;
+        } else if constexpr (Ns == 1 && (R % 2) == 0) {
             // column c owns R contiguous outputs at (C t + c) R: the thread's P
             // outputs are the run [P t, P t + P), i.e. pad adds exactly 2 t.
             cf *base = lds + (unsigned)((P + 2) * t);
@@ -415,7 +426,9 @@ struct FftKernel {
     static __device__ __forceinline__ void lds_read(const cf *lds, cf *v, int t) {
         constexpr int R = Cfg::R(I), C = Cfg::C(I);
         constexpr int STRIDE = N / R;
-        if constexpr (STRIDE % P == 0) {
+        if constexpr (Cfg::ABL & 2) {
+            return;
+        } else if constexpr (STRIDE % P == 0) {
             const cf *base = lds + Cfg::pad(C * t);
 #pragma unroll
             for (int r = 0; r < R; ++r) ld_c<C>(base + r * (STRIDE + 2 * (STRIDE / P)), v + r * C);
@@ -435,7 +448,7 @@ struct FftKernel {
             const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
             apply_twiddles<I>(v, tw, t);
 #pragma unroll
-            for (int c = 0; c < C; ++c) dft_regs<R, C>(v + c);
+            for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0>(v + c);
             lds_write<I>(lds, v, t);
             frame_sync();
             middle_pass<I + 1>(lds, lds_all, v, a, t);
@@ -508,7 +521,9 @@ struct FftKernel {
                         m[c] = __builtin_amdgcn_sqrtf(p);
                     }
                 }
-                if (patched && r == RL / 2 && t == 0) {
+                if constexpr (Cfg::ABL & 1) {
+                    if (m[0] == -1.0f) st_out<CL>(o + r * NsL, m);  // never true: sqrt >= 0
+                } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) o[r * NsL + c] = m[c];
                 } else {
@@ -585,7 +600,7 @@ struct FftKernel {
             // are converted and stay in flight during the whole transform
             if (live_n) load_raw(a, frame_n, t, raw);
 #pragma unroll
-            for (int c = 0; c < C0; ++c) dft_regs<R0, C0>(v + c);
+            for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
             lds_write<0>(lds, v, t);
             frame_sync();
             middle_pass<1>(lds, lds_all, v, a, t);
@@ -601,13 +616,16 @@ struct FftKernel {
 #pragma unroll
                 for (int r = 1; r < RL; ++r) {
 #pragma unroll
-                    for (int c = 0; c < CL; ++c) v[r * CL + c] = pk_cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
+                    for (int c = 0; c < CL; ++c) {
+                        if constexpr (Cfg::ABL & 4) v[r * CL + c] += twl[(r - 1) * CL + c];
+                        else v[r * CL + c] = pk_cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
+                    }
                 }
             } else {
                 apply_twiddles<LAST>(v, a.tw[LAST], t);
             }
 #pragma unroll
-            for (int c = 0; c < CL; ++c) dft_regs<RL, CL>(v + c);
+            for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
             if (live) epilogue(a, frame, v, t);
 
             frame = frame_n;

@@ -1,4 +1,4 @@
-// N = 8192: 256 lanes x 32 points, 16 x 32 x 16, two LDS exchanges.
+// N = 8192: 256 lanes x 32 points, 16 x 16 x 32, two LDS exchanges.
 #include "fsea_configs.h"
 #include "fsea_registry.h"
 FSEA_DEFINE_KERNEL(fsea_fft8192, "", FSEA_CFG_8192)

@@ -14,10 +14,11 @@ from frequensea_amd import fsea  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 VARIANTS = {
-    8192: ["", "A", "B", "D", "E", "F", "notwl", "notwr"],
+    8192: ["", "A", "B", "D", "E", "F", "notwl", "notwr",
+           "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu"],
     1024: ["", "B", "C", "D"],
-    4096: ["", "B"],
-    128: [""], 256: [""], 512: [""], 2048: [""], 16384: [""],
+    4096: ["", "B", "C", "D"],
+    128: [""], 256: [""], 512: [""], 2048: ["", "B", "C"], 16384: ["", "B"],
 }
 TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch
 
@@ -55,7 +56,7 @@ def main():
             print("N=%-5d variant=%-6s %-22s grid=%-5d wg=%-4d lds=%-6d  %8.3f ms  %7.1f Mframes/s  %7.1f GB/s  "
                   "%.1f%% of 8 TB/s  rel=%.1e %s" % (n, var or "-", plan.kernel_name, grid[0], grid[1], grid[2], ms,
                                                       frames / ms / 1e3, gbs, gbs / 80.0, rel,
-                                                      "OK" if rel < 1e-6 else "MISMATCH"))
+                                                      "OK" if rel < 1e-6 else ("ablation" if var.startswith("abl_") else "MISMATCH")))
             plan.close()
 
 

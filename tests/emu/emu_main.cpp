@@ -86,6 +86,11 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
         EMU_VARIANT(1024, "C", FSEA_CFG_1024_C)
         EMU_VARIANT(1024, "D", FSEA_CFG_1024_D)
         EMU_VARIANT(4096, "B", FSEA_CFG_4096_B)
+        EMU_VARIANT(4096, "C", FSEA_CFG_4096_C)
+        EMU_VARIANT(4096, "D", FSEA_CFG_4096_D)
+        EMU_VARIANT(16384, "B", FSEA_CFG_16384_B)
+        EMU_VARIANT(2048, "B", FSEA_CFG_2048_B)
+        EMU_VARIANT(2048, "C", FSEA_CFG_2048_C)
         return -2;
     }
     switch (n) {

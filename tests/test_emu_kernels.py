@@ -103,7 +103,8 @@ def test_edge_inputs():
 
 @pytest.mark.parametrize("n,variant", [(8192, "A"), (8192, "B"), (8192, "D"), (8192, "E"), (8192, "F"),
                                        (8192, "notwl"), (8192, "notwr"), (1024, "B"), (1024, "C"), (1024, "D"),
-                                       (4096, "B")])
+                                       (4096, "B"), (4096, "C"), (4096, "D"), (16384, "B"), (2048, "B"),
+                                       (2048, "C")])
 def test_tuning_variants(n, variant):
     """Every kernel variant compiled into libfsea_hip.so (fsea_plan_create_variant) stays correct."""
     nf = 9 if n <= 1024 else 3
