@@ -21,6 +21,7 @@ VARIANTS = {
     128: [""], 256: [""], 512: [""], 2048: ["", "B", "C"], 16384: ["", "B"],
 }
 TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch
+ROUNDS = 7
 
 
 def dev_alloc(nbytes):
@@ -40,23 +41,37 @@ def main():
     for n in sizes:
         frames = TOTAL_SAMPLES // n
         want = O.rows(host[: 2 * n * 3], 3, n)
+        plans = []
         for var in VARIANTS.get(n, [""]):
             try:
-                plan = fsea.Plan(n, variant=var)
+                plans.append((var, fsea.Plan(n, variant=var)))
             except fsea.FseaError as e:
                 print("N=%d variant=%-6s unavailable: %s" % (n, var, e))
-                continue
-            plan.time_device(d_in, frames, d_out, 3)                      # warm-up
-            ms = min(plan.time_device(d_in, frames, d_out, 10) for _ in range(3))
-            got = np.empty((3, n), np.float32)
-            fsea._check(L.fsea_copy_to_host(0, got.ctypes.data, d_out, got.nbytes))
-            rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        # warm the clocks, then interleave the variants over several rounds so that order,
+        # DVFS state and neighbours affect every variant alike; report median and best
+        for _, plan in plans:
+            plan.time_device(d_in, frames, d_out, 20)
+        times = {var: [] for var, _ in plans}
+        rels = {}
+        for rnd in range(ROUNDS):
+            order = plans if rnd % 2 == 0 else plans[::-1]
+            for var, plan in order:
+                times[var].append(plan.time_device(d_in, frames, d_out, 10))
+                if rnd == 0:
+                    got = np.empty((3, n), np.float32)
+                    fsea._check(L.fsea_copy_to_host(0, got.ctypes.data, d_out, got.nbytes))
+                    rels[var] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        for var, plan in plans:
+            ms = float(np.median(times[var]))
+            best = float(np.min(times[var]))
+            rel = rels[var]
             gbs = 6.0 * n * frames / (ms * 1e-3) / 1e9
             grid = plan.grid(frames)
-            print("N=%-5d variant=%-6s %-22s grid=%-5d wg=%-4d lds=%-6d  %8.3f ms  %7.1f Mframes/s  %7.1f GB/s  "
-                  "%.1f%% of 8 TB/s  rel=%.1e %s" % (n, var or "-", plan.kernel_name, grid[0], grid[1], grid[2], ms,
-                                                      frames / ms / 1e3, gbs, gbs / 80.0, rel,
-                                                      "OK" if rel < 1e-6 else ("ablation" if var.startswith("abl_") else "MISMATCH")))
+            print("N=%-5d variant=%-11s %-28s grid=%-4d wg=%-3d lds=%-6d median %7.3f ms (best %7.3f)  %7.1f Mframes/s  "
+                  "%6.1f GB/s  %4.1f%% of 8 TB/s  rel=%.1e %s"
+                  % (n, var or "-", plan.kernel_name, grid[0], grid[1], grid[2], ms, best, frames / ms / 1e3, gbs,
+                     gbs / 80.0, rel,
+                     "OK" if rel < 1e-6 else ("ablation" if var.startswith("abl_") else "MISMATCH")))
             plan.close()
 
 
