@@ -540,28 +540,6 @@ struct FftKernel {
         const int t = tid % T;
         cf *lds = lds_all + slot * Cfg::LDS_FRAME;
 
-        // middle-pass twiddle tables -> LDS, once per workgroup
-        if constexpr (Cfg::TWL && NP > 2) {
-            constexpr int TOT = Cfg::LDS_TOTAL - FPW * Cfg::LDS_FRAME;
-            cf *dst = lds_all + FPW * Cfg::LDS_FRAME;
-            for (int i = tid; i < TOT; i += Cfg::WG) {
-                // tables of passes 1..LAST-1 are contiguous in the global image too
-                dst[i] = a.tw[1][i];
-            }
-            __syncthreads();
-        }
-
-        // last-pass twiddles in registers for the lifetime of the workgroup
-        cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
-        if constexpr (Cfg::TWR) {
-#pragma unroll
-            for (int r = 1; r < RL; ++r) ld_c<CL>(a.tw[LAST] + (r - 1) * NsL + CL * t, twl + (r - 1) * CL);
-            if constexpr (PRESCALED) {
-#pragma unroll
-                for (int i = 0; i < (RL - 1) * CL; ++i) twl[i] = twl[i] * cf{SC, SC};
-            }
-        }
-
         // XCD-aware unit mapping: workgroup b runs on XCD b % 8; give each XCD a
         // contiguous range of frames so that overlapped (hop < N) frames share L2.
         const size_t units = (a.n_frames + FPW - 1) / FPW;
@@ -581,7 +559,31 @@ struct FftKernel {
         Raw raw[R0];
         size_t frame = u * FPW + slot;
         bool live = (u < u_end) && (frame < a.n_frames);
+        // Prologue: every independent request is issued before the first wait, so that
+        // the latencies overlap: frame 0's bytes (HBM starts streaming at once), the
+        // register-resident last-pass twiddles, then the middle-pass tables for LDS.
         if (live) load_raw(a, frame, t, raw);
+
+        cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
+        if constexpr (Cfg::TWR) {
+#pragma unroll
+            for (int r = 1; r < RL; ++r) ld_c<CL>(a.tw[LAST] + (r - 1) * NsL + CL * t, twl + (r - 1) * CL);
+        }
+
+        if constexpr (Cfg::TWL && NP > 2) {
+            constexpr int TOT = Cfg::LDS_TOTAL - FPW * Cfg::LDS_FRAME;
+            cf *dst = lds_all + FPW * Cfg::LDS_FRAME;
+            for (int i = tid; i < TOT; i += Cfg::WG) {
+                // tables of passes 1..LAST-1 are contiguous in the global image too
+                dst[i] = a.tw[1][i];
+            }
+            __syncthreads();
+        }
+
+        if constexpr (PRESCALED) {
+#pragma unroll
+            for (int i = 0; i < (RL - 1) * CL; ++i) twl[i] = twl[i] * cf{SC, SC};
+        }
 
         for (; u < u_end; u += u_step) {
             const size_t un = u + u_step;
