@@ -123,6 +123,87 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
                 sample=sample, host_head=np.roll(host, 0)[: 2 * 4 * hop + 2 * n])
 
 
+def run_broad(args, rank, world, dist, torch, steps, warmup):
+    """the fft-batch-broad sweep -- 512 centre frequencies x 256 frames x 4096-pt,
+    u8 dB tiles (DB5 + DC fix), centre frequencies sharded over the ranks, tiles gathered to rank 0 over
+    RCCL and max-composited into the stitched image (c/fft-stitch-broad.c).  Strong scaling: the sweep
+    is fixed, a step is the whole sweep including gather and stitch."""
+    from frequensea_amd import fsea, sweep
+
+    n, rows, tiles = 4096, 256, 512
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lo, hi = sweep.partition(tiles, world, rank)
+    plan = fsea.Plan(n, hop=n, mode=fsea.MODE_DB5_U8_DCFIX, device=dev.index)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4000000 + lo)
+    samples = (hi - lo) * rows * n
+    iq = torch.empty(2 * samples, dtype=torch.int8, device=dev)
+    chunk = 1 << 24
+    for s0 in range(0, 2 * samples, chunk):                     # int8 Gaussian sigma=20, generated on device
+        e0 = min(2 * samples, s0 + chunk)
+        iq[s0:e0] = torch.clamp(torch.round(torch.randn(e0 - s0, generator=gen, device=dev) * 20.0), -128, 127).to(torch.int8)
+    px = torch.empty((hi - lo, rows, n), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def make_tiles(a, b):
+        plan.exec_device(iq.data_ptr(), (b - a) * rows, px.data_ptr(), flip=True, stream=stream)   # one launch
+        return px
+
+    def composite(image, tile, x):
+        fsea.composite_max_device(image.data_ptr(), tile.data_ptr(), x, 0, n, rows, image.shape[1], n,
+                                  device=dev.index, stream=stream)
+
+    def step():
+        return sweep.run_sweep(tiles, (rows, n), make_tiles, composite, dist=dist, torch=torch, device=dev)
+
+    for _ in range(max(warmup, 1)):
+        img = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    # FFT kernel alone on this rank's shard (HIP events on the launch stream)
+    kernel_ms = plan.time_device(iq.data_ptr(), (hi - lo) * rows, px.data_ptr(), 10, stream=stream)
+    if dist is not None:
+        tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(tt[0]), float(tt[1])
+    check = None
+    if rank == 0:
+        from oracle import oracle as O
+        head = iq[: 2 * n * 2].cpu().numpy().view(np.uint8)
+        want = O.rows(head, 2, n, mode=O.MODE_DB5_U8_DCFIX)
+        got = img[:2, :n].cpu().numpy()
+        check = int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())
+        if check > 1:
+            raise SystemExit("bench broad: stitched pixels differ from the oracle by %d" % check)
+    frames_total = tiles * rows
+    shard_frames = (hi - lo) * rows
+    alg = (2 * n + n) * shard_frames
+    line = {
+        "metric": "fft_frames_per_sec_broad_sweep_n4096", "value": frames_total * steps / wall, "unit": "frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "broad: 512 centre freqs x 256 frames x 4096-pt, DB5_U8_DCFIX tiles, gather to "
+                               "rank 0 + max-composite (resident input + gather regime)",
+                   "parallelism": "centre frequencies sharded x%d, one gather of u8 tiles" % world},
+        "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": plan.kernel_name, "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg},
+        "stitched_pixel_max_diff_vs_oracle": check,
+    }
+    plan.close()
+    return line
+
+
 def cpu_baseline(n, hop, cores, budget_s):
     """Oracle port timed on this host (bounded sample: about `budget_s` core-seconds)."""
     from oracle import oracle as O
@@ -151,7 +232,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="batch8192x4096", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="batch8192x4096", choices=sorted(WORKLOADS) + ["broad"])
     ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -175,6 +256,14 @@ def main():
     if args.gpus != world:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    if args.workload == "broad":
+        line = run_broad(args, rank, world, dist, torch, max(1, args.steps // 20), max(1, args.warmup // 10))
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     res = run_gpu(args, args.workload, rank, world, dist, torch, args.steps, args.warmup, args.sets)
     n, frames, hop = res["n"], res["frames"], res["hop"]
