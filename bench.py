@@ -153,8 +153,13 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         fsea.composite_max_device(image.data_ptr(), tile.data_ptr(), x, 0, n, rows, image.shape[1], n,
                                   device=dev.index, stream=stream)
 
+    def composite_stack(image, stack, count, first_x):
+        fsea.stitch_tiles_device(image.data_ptr(), stack.data_ptr(), count, first_x, n, n, rows, image.shape[1],
+                                 device=dev.index, stream=stream)
+
     def step():
-        return sweep.run_sweep(tiles, (rows, n), make_tiles, composite, dist=dist, torch=torch, device=dev)
+        return sweep.run_sweep(tiles, (rows, n), make_tiles, composite, dist=dist, torch=torch, device=dev,
+                               composite_stack=composite_stack)
 
     for _ in range(max(warmup, 1)):
         img = step()

@@ -12,5 +12,5 @@ bench.py and scripting; it contains no compute of its own and no CPU fallback.
 """
 from .fsea import (  # noqa: F401
     MODE_MAG_F32, MODE_DB10_U8, MODE_DB5_U8_DCFIX, MODE_COMPLEX_F32, MODE_MAG_NODC_F32, MODE_DB_F32,
-    FseaError, Plan, build, device_count, hip_lib, composite_max_device, lib_path,
+    FseaError, Plan, build, device_count, hip_lib, composite_max_device, stitch_tiles_device, lib_path,
 )

@@ -118,6 +118,37 @@ __global__ void fsea_composite_max_kernel(uint8_t *dst, const uint8_t *src, uint
     }
 }
 
+// Many tiles in one launch: tile k (tiles contiguous, [k][y][x]) is max-composited at
+// x0 + k*step.  Only tiles with k % stride_k == phase are touched, so that overlapping
+// neighbours (step < width) are handled by separate launches without a race.
+__global__ void fsea_stitch_tiles_kernel(uint8_t *dst, const uint8_t *tiles, uint32_t n_tiles, uint32_t x0,
+                                         uint32_t step, uint32_t width, uint32_t height, uint32_t dst_stride,
+                                         uint32_t stride_k, uint32_t phase) {
+    const uint32_t k = (blockIdx.z * stride_k) + phase;
+    if (k >= n_tiles) return;
+    const uint32_t x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (x4 >= width) return;
+    for (uint32_t y = blockIdx.y; y < height; y += gridDim.y) {
+        uint8_t *d = dst + (size_t)y * dst_stride + x0 + (size_t)k * step + x4;
+        const uint8_t *s = tiles + ((size_t)k * height + y) * width + x4;
+        const bool vec = (x4 + 4 <= width) && ((reinterpret_cast<uintptr_t>(d) & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(s) & 3) == 0);
+        if (vec) {
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(d);
+            const uint32_t b = *reinterpret_cast<const uint32_t *>(s);
+            uint32_t r = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t ab = (a >> (8 * q)) & 0xff, bb = (b >> (8 * q)) & 0xff;
+                r |= (ab > bb ? ab : bb) << (8 * q);
+            }
+            *reinterpret_cast<uint32_t *>(d) = r;
+        } else {
+            for (uint32_t q = 0; q < 4 && x4 + q < width; ++q) d[q] = d[q] > s[q] ? d[q] : s[q];
+        }
+    }
+}
+
 __global__ void fsea_sum_f32_kernel(const float *x, size_t n, double *acc) {
     double s = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -408,6 +439,31 @@ int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x, ui
     hipLaunchKernelGGL(fsea_composite_max_kernel, grid, dim3(bx), 0, static_cast<hipStream_t>(stream),
                        static_cast<uint8_t *>(d_dst), static_cast<const uint8_t *>(d_src), dst_x, dst_y, width, height,
                        dst_stride, src_stride);
+    FSEA_HIP(hipGetLastError());
+    return FSEA_OK;
+}
+
+int fsea_stitch_tiles_device(void *d_image, const void *d_tiles, uint32_t n_tiles, uint32_t first_x,
+                             uint32_t width_step, uint32_t width, uint32_t height, uint32_t image_stride, int device,
+                             void *stream) {
+    if (!d_image || !d_tiles) return fail(FSEA_EINVAL, "NULL buffer");
+    if (n_tiles == 0 || width == 0 || height == 0) return FSEA_OK;
+    if (width_step == 0) return fail(FSEA_EINVAL, "width_step must be positive");
+    if ((size_t)first_x + (size_t)(n_tiles - 1) * width_step + width > image_stride) {
+        return fail(FSEA_EINVAL, "tiles do not fit the image row stride");
+    }
+    FSEA_HIP(hipSetDevice(device));
+    // tiles k and k + m overlap when m * step < width: m phases keep every launch race-free
+    const uint32_t phases = (width + width_step - 1) / width_step;
+    const unsigned bx = 64;
+    for (uint32_t ph = 0; ph < phases; ++ph) {
+        const uint32_t cnt = (n_tiles > ph) ? (n_tiles - ph + phases - 1) / phases : 0;
+        if (cnt == 0) continue;
+        dim3 grid((width / 4 + bx) / bx, height < 1024 ? height : 1024, cnt);
+        hipLaunchKernelGGL(fsea_stitch_tiles_kernel, grid, dim3(bx), 0, static_cast<hipStream_t>(stream),
+                           static_cast<uint8_t *>(d_image), static_cast<const uint8_t *>(d_tiles), n_tiles, first_x,
+                           width_step, width, height, image_stride, phases, ph);
+    }
     FSEA_HIP(hipGetLastError());
     return FSEA_OK;
 }

@@ -209,39 +209,70 @@ __device__ __forceinline__ void st_c(cf *p, const cf *src) {
     }
 }
 
-// C consecutive output elements (float, uint8_t or complex) at p.
+// ---------------------------------------------------------------------------
+// Global memory goes through buffer resources: the 64-bit base and the bounds live
+// in four SGPRs, a lane contributes one 32-bit byte offset, and the per-row part of
+// the address is a scalar offset -- no 64-bit VALU address arithmetic, and accesses
+// outside [0, num_records) return zero / are dropped in hardware, which is what a
+// workgroup slot without a frame (ragged last unit) relies on.
+// ---------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t buffer_window(const void *base, size_t off, size_t total) {
+    const size_t rem = total > off ? total - off : 0;
+    char *p = const_cast<char *>(static_cast<const char *>(base)) + (rem ? off : 0);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, rem > 0xffffffffull ? 0xffffffffu : (uint32_t)rem, 0x00020000);
+}
+
+typedef uint32_t u32x2 __attribute__((vector_size(8)));
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+// C consecutive f32 / u8 / complex outputs at byte offset voff (+ scalar soff)
 template <int C>
-__device__ __forceinline__ void st_out(float *p, const float *v) {
+__device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, const float *v) {
     if constexpr (C == 1) {
-        p[0] = v[0];
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(v[0]), rs, voff, soff, 0);
     } else if constexpr (C == 2) {
-        *reinterpret_cast<cf *>(p) = cf{v[0], v[1]};
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0]), f2u(v[1])}, rs, voff, soff, 0);
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
-            *reinterpret_cast<cf2 *>(p + c) = cf2{v[c], v[c + 1], v[c + 2], v[c + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c]), f2u(v[c + 1]), f2u(v[c + 2]), f2u(v[c + 3])}, rs,
+                                                   voff + 4 * c, soff, 0);
         }
     }
 }
 
 template <int C>
-__device__ __forceinline__ void st_out(uint8_t *p, const uint8_t *v) {
+__device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, const uint8_t *v) {
     if constexpr (C == 1) {
-        p[0] = v[0];
+        __builtin_amdgcn_raw_buffer_store_b8(v[0], rs, voff, soff, 0);
     } else if constexpr (C == 2) {
-        *reinterpret_cast<uint16_t *>(p) = (uint16_t)(v[0] | (v[1] << 8));
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(v[0] | (v[1] << 8)), rs, voff, soff, 0);
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
-            *reinterpret_cast<uint32_t *>(p + c) =
-                (uint32_t)v[c] | ((uint32_t)v[c + 1] << 8) | ((uint32_t)v[c + 2] << 16) | ((uint32_t)v[c + 3] << 24);
+            const uint32_t w = (uint32_t)v[c] | ((uint32_t)v[c + 1] << 8) | ((uint32_t)v[c + 2] << 16) |
+                               ((uint32_t)v[c + 3] << 24);
+            __builtin_amdgcn_raw_buffer_store_b32(w, rs, voff + c, soff, 0);
         }
     }
 }
 
 template <int C>
-__device__ __forceinline__ void st_out(cf *p, const cf *v) {
-    st_c<C>(p, v);
+__device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, const cf *v) {
+    if constexpr (C == 1) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0][0]), f2u(v[0][1])}, rs, voff, soff, 0);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c][0]), f2u(v[c][1]), f2u(v[c + 1][0]), f2u(v[c + 1][1])},
+                                                   rs, voff + 8 * c, soff, 0);
+        }
+    }
 }
 
 // Raw input words of pass 0: C samples per row.
@@ -331,22 +362,40 @@ struct FftKernel {
         }
     }
 
-    static __device__ __forceinline__ void load_raw(const FftArgs &a, size_t frame, int t, Raw *raw) {
+    static constexpr uint32_t IN_BPS = (IN == IN_U8) ? 2 : 8;  // input bytes per complex sample
+
+    // voff: this lane's byte offset inside the unit's window (slot * hop + C0 t samples)
+    static __device__ __forceinline__ void load_raw(rsrc_t rs, uint32_t voff, Raw *raw) {
         constexpr int STRIDE = N / R0;
-        if constexpr (IN == IN_U8) {
-            const uint8_t *base = static_cast<const uint8_t *>(a.in) + 2 * (frame * a.hop + (size_t)(C0 * t));
 #pragma unroll
-            for (int r = 0; r < R0; ++r) {
-                const uint8_t *p = base + 2 * (size_t)(r * STRIDE);
-                if constexpr (C0 == 1) raw[r].w = *reinterpret_cast<const uint16_t *>(p);
-                if constexpr (C0 == 2) raw[r].w = *reinterpret_cast<const uint32_t *>(p);
-                if constexpr (C0 == 4) raw[r].w = *reinterpret_cast<const uint2 *>(p);
-                if constexpr (C0 == 8) raw[r].w = *reinterpret_cast<const uint4 *>(p);
+        for (int r = 0; r < R0; ++r) {
+            const uint32_t soff = (uint32_t)(r * STRIDE) * IN_BPS;
+            if constexpr (IN == IN_U8) {
+                if constexpr (C0 == 1) raw[r].w = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
+                if constexpr (C0 == 2) raw[r].w = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+                if constexpr (C0 == 4) {
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+                    raw[r].w.x = q[0];
+                    raw[r].w.y = q[1];
+                }
+                if constexpr (C0 == 8) {
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+                    raw[r].w.x = q[0];
+                    raw[r].w.y = q[1];
+                    raw[r].w.z = q[2];
+                    raw[r].w.w = q[3];
+                }
+            } else if constexpr (C0 == 1) {
+                const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+                raw[r].w[0] = cf{u2f(q[0]), u2f(q[1])};
+            } else {
+#pragma unroll
+                for (int c = 0; c < C0; c += 2) {
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 8 * c, soff, 0);
+                    raw[r].w[c] = cf{u2f(q[0]), u2f(q[1])};
+                    raw[r].w[c + 1] = cf{u2f(q[2]), u2f(q[3])};
+                }
             }
-        } else {
-            const cf *base = static_cast<const cf *>(a.in) + frame * a.hop + (size_t)(C0 * t);
-#pragma unroll
-            for (int r = 0; r < R0; ++r) ld_c<C0>(base + r * STRIDE, raw[r].w);
         }
     }
 
@@ -455,11 +504,15 @@ struct FftKernel {
         }
     }
 
-    // fused epilogue for the row held as v[r*CL + c] = bin CL t + c + r NsL
-    static __device__ __forceinline__ void epilogue(const FftArgs &a, size_t frame, cf *v, int t) {
+    static __device__ __forceinline__ uint32_t elem_bytes(int mode) {
+        return (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) ? 1u : (mode == MODE_COMPLEX ? 8u : 4u);
+    }
+
+    // fused epilogue for the row held as v[r*CL + c] = bin CL t + c + r NsL.
+    // out: window of this unit's rows; lane_elem = slot * N + CL * t (first bin of this lane)
+    static __device__ __forceinline__ void epilogue(int mode, rsrc_t out, uint32_t lane_elem, cf *v, int t) {
         constexpr float SE = PRESCALED ? 1.0f : SC;  // scale still to apply to re / im
         constexpr float SE2 = SE * SE;
-        const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
         const bool patched = (mode == MODE_MAG) || (mode == MODE_DB5_U8_DCFIX);
         // Offset-binary input carries a DC term 0.5 per component, which the
         // (-1)^n centring moves to bin N/2 exactly: 0.5 N (1 + i).  The kernel
@@ -469,23 +522,22 @@ struct FftKernel {
             const float dc = (PRESCALED ? 0.5f : 128.0f) * (float)N;
             v[(RL / 2) * CL] += cf{dc, dc};
         }
-        const size_t row = frame * (size_t)N;
-        const int k0 = CL * t;
         if (mode == MODE_COMPLEX) {
-            cf *o = static_cast<cf *>(a.out) + row + k0;
+            const uint32_t voff = lane_elem * 8u;
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
                 cf z[CL];
 #pragma unroll
                 for (int c = 0; c < CL; ++c) z[c] = v[r * CL + c] * cf{SE, SE};
-                st_out<CL>(o + r * NsL, z);
+                bst<CL>(out, voff, (uint32_t)(r * NsL) * 8u, z);
             }
         } else if (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) {
             // 10*log10(p + 1e-20) * s = (10 s log10(2)) * log2(p + 1e-20)
             const float kdb = (mode == MODE_DB10_U8 ? 100.0f : 50.0f) * 0.30102999566398120f;
-            uint8_t *o = static_cast<uint8_t *>(a.out) + row + k0;
+            const uint32_t voff = lane_elem;
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
+                const uint32_t soff = (uint32_t)(r * NsL);
                 uint8_t px[CL];
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
@@ -499,16 +551,17 @@ struct FftKernel {
                 }
                 if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
-                    for (int c = 1; c < CL; ++c) o[r * NsL + c] = px[c];
+                    for (int c = 1; c < CL; ++c) bst<1>(out, voff + c, soff, px + c);
                 } else {
-                    st_out<CL>(o + r * NsL, px);
+                    bst<CL>(out, voff, soff, px);
                 }
-                if (patched && r == RL / 2 - 1 && t == T - 1) o[r * NsL + CL] = px[CL - 1];
+                if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + CL, soff, px + (CL - 1));
             }
         } else {
-            float *o = static_cast<float *>(a.out) + row + k0;
+            const uint32_t voff = lane_elem * 4u;
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
+                const uint32_t soff = (uint32_t)(r * NsL) * 4u;
                 float m[CL];
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
@@ -522,22 +575,22 @@ struct FftKernel {
                     }
                 }
                 if constexpr (Cfg::ABL & 1) {
-                    if (m[0] == -1.0f) st_out<CL>(o + r * NsL, m);  // never true: sqrt >= 0
+                    if (m[0] == -1.0f) bst<CL>(out, voff, soff, m);  // never true: sqrt >= 0
                 } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
-                    for (int c = 1; c < CL; ++c) o[r * NsL + c] = m[c];
+                    for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);
                 } else {
-                    st_out<CL>(o + r * NsL, m);
+                    bst<CL>(out, voff, soff, m);
                 }
-                if (patched && r == RL / 2 - 1 && t == T - 1) o[r * NsL + CL] = m[CL - 1];
+                if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + 4 * CL, soff, m + (CL - 1));
             }
         }
     }
 
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
         const int tid = threadIdx.x;
-        const int slot = tid / T;
-        const int t = tid % T;
+        const int slot = (FPW == 1) ? 0 : tid / T;  // FPW == 1: the frame index is wave-uniform
+        const int t = (FPW == 1) ? tid : tid % T;
         cf *lds = lds_all + slot * Cfg::LDS_FRAME;
 
         // XCD-aware unit mapping: workgroup b runs on XCD b % 8; give each XCD a
@@ -556,13 +609,18 @@ struct FftKernel {
             u_step = G;
         }
 
-        Raw raw[R0];
-        size_t frame = u * FPW + slot;
-        bool live = (u < u_end) && (frame < a.n_frames);
+        const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
+        const uint32_t esz = elem_bytes(mode);
+        const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
+        const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
+        const uint32_t in_voff = (uint32_t)IN_BPS * ((uint32_t)slot * (uint32_t)a.hop + (uint32_t)(C0 * t));
+        const uint32_t out_elem = (uint32_t)slot * (uint32_t)N + (uint32_t)(CL * t);
+
         // Prologue: every independent request is issued before the first wait, so that
-        // the latencies overlap: frame 0's bytes (HBM starts streaming at once), the
+        // the latencies overlap: unit 0's bytes (HBM starts streaming at once), the
         // register-resident last-pass twiddles, then the middle-pass tables for LDS.
-        if (live) load_raw(a, frame, t, raw);
+        Raw raw[R0];
+        load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < u_end ? total_in : 0), in_voff, raw);
 
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
         if constexpr (Cfg::TWR) {
@@ -587,20 +645,15 @@ struct FftKernel {
 
         for (; u < u_end; u += u_step) {
             const size_t un = u + u_step;
-            const size_t frame_n = un * FPW + slot;
-            const bool live_n = (un < u_end) && (frame_n < a.n_frames);
 
+            // A slot without a frame (ragged last unit) still runs the barriers; it simply
+            // transforms whatever bytes it holds and stores nothing.
             cf v[P];
-            if (live) {
 #pragma unroll
-                for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < P; ++i) v[i] = cf{0.f, 0.f};
-            }
+            for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
             // prefetch: the next frame's bytes are requested as soon as this frame's
             // are converted and stay in flight during the whole transform
-            if (live_n) load_raw(a, frame_n, t, raw);
+            load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < u_end ? total_in : 0), in_voff, raw);
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
             lds_write<0>(lds, v, t);
@@ -628,10 +681,7 @@ struct FftKernel {
             }
 #pragma unroll
             for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
-            if (live) epilogue(a, frame, v, t);
-
-            frame = frame_n;
-            live = live_n;
+            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
         }
     }
 };

@@ -24,7 +24,7 @@ EXPORTS = [
     "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_create_variant",
     "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device",
     "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_mean_magnitude_u8_device",
-    "fsea_composite_max_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
+    "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
     "fsea_copy_to_host", "fsea_stream_synchronize", "fsea_time_exec_u8_device",
     "fsea_plan_kernel_name", "fsea_last_error_string",
 ]
@@ -74,6 +74,7 @@ def hip_lib():
         L.fsea_exec_f64_host.argtypes = [vp, vp, sz, vp]
         L.fsea_mean_magnitude_u8_device.argtypes = [vp, vp, sz, ci, ctypes.POINTER(ctypes.c_double), vp]
         L.fsea_composite_max_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 6 + [ci, vp]
+        L.fsea_stitch_tiles_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 6 + [ci, vp]
         L.fsea_device_alloc.argtypes = [ci, sz, ctypes.POINTER(vp)]
         L.fsea_device_free.argtypes = [ci, vp]
         L.fsea_copy_to_device.argtypes = [ci, vp, vp, sz]
@@ -184,3 +185,9 @@ class Plan:
 def composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride, src_stride, device=0, stream=0):
     _check(hip_lib().fsea_composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride,
                                                src_stride, device, stream or None))
+
+
+def stitch_tiles_device(d_image, d_tiles, n_tiles, first_x, width_step, width, height, image_stride, device=0,
+                        stream=0):
+    _check(hip_lib().fsea_stitch_tiles_device(d_image, d_tiles, n_tiles, first_x, width_step, width, height,
+                                              image_stride, device, stream or None))

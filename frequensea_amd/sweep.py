@@ -26,11 +26,14 @@ def stitched_width(fft_size, n_tiles, width_step):
     return fft_size + (n_tiles - 1) * width_step if n_tiles else 0
 
 
-def run_sweep(n_tiles, tile_shape, make_tiles, composite, dist=None, torch=None, device=None, width_step=None):
+def run_sweep(n_tiles, tile_shape, make_tiles, composite, dist=None, torch=None, device=None, width_step=None,
+              composite_stack=None):
     """Shard `n_tiles` centre frequencies over the ranks of `dist`, gather the tiles to rank 0 and stitch.
 
     make_tiles(lo, hi) -> torch.uint8 tensor [hi-lo, H, N] on `device` (this rank's tiles, in order)
     composite(image, tile, x)   max-composites one [H, N] tile into image[:, x:x+N] (rank 0 only)
+    composite_stack(image, stack, count, first_x)   optional: all `count` tiles of one rank's stack at
+                                once (tile k at first_x + k * width_step); used instead of `composite`
     Returns the stitched [H, W] torch.uint8 image on rank 0, None elsewhere.
     """
     h, n = tile_shape
@@ -56,6 +59,9 @@ def run_sweep(n_tiles, tile_shape, make_tiles, composite, dist=None, torch=None,
         return None
     image = torch.zeros((h, stitched_width(n, n_tiles, width_step)), dtype=torch.uint8, device=device)
     for r, (a, b) in enumerate(per_rank):
+        if composite_stack is not None:
+            composite_stack(image, gathered[r], b - a, a * width_step)
+            continue
         for k in range(b - a):
             composite(image, gathered[r][k], (a + k) * width_step)
     return image

@@ -120,6 +120,14 @@ int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x,
                               uint32_t dst_stride, uint32_t src_stride, int device,
                               void *stream);
 
+/* The whole stitch loop of c/fft-stitch*.c:167-189 for a contiguous stack of tiles
+ * ([k][y][x], each width x height): tile k is max-composited at x = first_x +
+ * k * width_step.  Overlapping neighbours (width_step < width) are processed in
+ * separate race-free launches.  Device pointers; asynchronous on `stream`. */
+int fsea_stitch_tiles_device(void *d_image, const void *d_tiles, uint32_t n_tiles, uint32_t first_x,
+                             uint32_t width_step, uint32_t width, uint32_t height,
+                             uint32_t image_stride, int device, void *stream);
+
 /* Small device-memory helpers so that C callers need no HIP headers. */
 int fsea_device_alloc(int device, size_t bytes, void **d_ptr);
 int fsea_device_free(int device, void *d_ptr);

@@ -44,5 +44,45 @@ static inline V emu_shuffle2(V a, V b, int i, int j) {
     return V{src[i], src[j]};
 }
 #define __builtin_shufflevector(a, b, i, j) emu_shuffle2(a, b, i, j)
+// buffer resources: base + byte count, with the hardware's range check (out-of-range loads
+// return zero, out-of-range stores are dropped)
+#include <cstring>
+struct emu_rsrc { char *base; uint32_t n; };
+typedef emu_rsrc __amdgpu_buffer_rsrc_t;
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) emu_rsrc{(char *)(p), (uint32_t)(n)}
+template <class T>
+static inline T emu_bload(emu_rsrc rs, uint32_t voff, uint32_t soff) {
+    T v;
+    std::memset(&v, 0, sizeof(T));
+    const uint64_t off = (uint64_t)voff + soff;
+    if (off + sizeof(T) <= rs.n) std::memcpy(&v, rs.base + off, sizeof(T));
+    return v;
+}
+template <class T>
+static inline void emu_bstore(T v, emu_rsrc rs, uint32_t voff, uint32_t soff) {
+    const uint64_t off = (uint64_t)voff + soff;
+    if (off + sizeof(T) <= rs.n) std::memcpy(rs.base + off, &v, sizeof(T));
+}
+typedef uint32_t emu_u32x2 __attribute__((vector_size(8)));
+typedef uint32_t emu_u32x4 __attribute__((vector_size(16)));
+// variadic so that brace-initialised vector arguments (commas) pass through the preprocessor
+static inline uint16_t emu_bl16(emu_rsrc rs, uint32_t v, uint32_t s, int) { return emu_bload<uint16_t>(rs, v, s); }
+static inline uint32_t emu_bl32(emu_rsrc rs, uint32_t v, uint32_t s, int) { return emu_bload<uint32_t>(rs, v, s); }
+static inline emu_u32x2 emu_bl64(emu_rsrc rs, uint32_t v, uint32_t s, int) { return emu_bload<emu_u32x2>(rs, v, s); }
+static inline emu_u32x4 emu_bl128(emu_rsrc rs, uint32_t v, uint32_t s, int) { return emu_bload<emu_u32x4>(rs, v, s); }
+static inline void emu_bs8(uint8_t d, emu_rsrc rs, uint32_t v, uint32_t s, int) { emu_bstore<uint8_t>(d, rs, v, s); }
+static inline void emu_bs16(uint16_t d, emu_rsrc rs, uint32_t v, uint32_t s, int) { emu_bstore<uint16_t>(d, rs, v, s); }
+static inline void emu_bs32(uint32_t d, emu_rsrc rs, uint32_t v, uint32_t s, int) { emu_bstore<uint32_t>(d, rs, v, s); }
+static inline void emu_bs64(emu_u32x2 d, emu_rsrc rs, uint32_t v, uint32_t s, int) { emu_bstore<emu_u32x2>(d, rs, v, s); }
+static inline void emu_bs128(emu_u32x4 d, emu_rsrc rs, uint32_t v, uint32_t s, int) { emu_bstore<emu_u32x4>(d, rs, v, s); }
+#define __builtin_amdgcn_raw_buffer_load_b16(...) emu_bl16(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_load_b32(...) emu_bl32(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_load_b64(...) emu_bl64(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_load_b128(...) emu_bl128(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b8(...) emu_bs8(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b16(...) emu_bs16(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b32(...) emu_bs32(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b64(...) emu_bs64(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b128(...) emu_bs128(__VA_ARGS__)
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_logf(x) log2f(x)

@@ -212,6 +212,13 @@ def test_mean_magnitude_gate_and_composite():
         d_t.free()                                      # hipFree synchronises the device
     got_img = d_img.download(np.uint8, want_img.shape)
     assert np.array_equal(got_img, want_img)
+    # the same stitch as one call over the contiguous tile stack (50 % overlap -> two phases)
+    d_img2 = DeviceBuffer(want_img.nbytes).upload(np.zeros_like(want_img))
+    d_stack = DeviceBuffer(3 * 64 * n).upload(np.stack(tiles))
+    fsea.stitch_tiles_device(d_img2.ptr, d_stack.ptr, 3, 0, n // 2, n, 64, width)
+    assert np.array_equal(d_img2.download(np.uint8, want_img.shape), want_img)
+    d_img2.free()
+    d_stack.free()
     d_in.free()
     d_img.free()
     plan.close()
