@@ -184,6 +184,7 @@ struct fsea_plan {
     fsea::cf *d_tw = nullptr;      // passes 1..np-1 concatenated
     size_t tw_off[4] = {0, 0, 0, 0};
     int num_cu = 0;
+    uint32_t skew = 0;
     int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0;
     // staging for the host-buffer entry points
     std::mutex mu;
@@ -232,6 +233,7 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.hop = (size_t)p->hop;
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
+    a.skew = p->skew;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     const int occ = (in_kind == fsea::IN_F32) ? p->occ_f32 : (mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8);
     p->entry->launch(in_kind, a, grid_for(p, occ, n_frames), s);
@@ -291,6 +293,7 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     p->entry = e;
     p->num_cu = prop.multiProcessorCount;
     p->kernel_name = (mode == FSEA_MODE_MAG_F32) ? e->name_u8_mag : e->name_u8;
+    if (const char *sk = std::getenv("FSEA_SKEW")) p->skew = (uint32_t)std::atoi(sk);  // tuning hook
 
     std::vector<fsea::TwPair> tw;
     fsea::build_twiddles(e->np, e->radix, tw, p->tw_off);

@@ -146,6 +146,8 @@ enum : int { IN_U8 = 0, IN_F32 = 1 };
 template <int N_, int T_, int FPW_, int WPE_, int NP_, int R0_, int R1_, int R2_ = 1, int R3_ = 1,
           bool TWL_ = true, bool TWR_ = true, int ABL_ = 0>
 struct FftCfg {
+    // ABL bits 8 / 16 are scheduling experiments, not ablations: raise the wave priority
+    // (s_setprio 1) around the LDS phases (8) or around the butterfly phases (16).
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
     static constexpr int ABL = ABL_;
@@ -177,6 +179,7 @@ struct FftArgs {
     size_t hop;           // samples between frame starts
     uint32_t xormask;     // u8 input: 0 when flip (raw int8), 0x80808080 otherwise
     int mode;             // MODE_*
+    uint32_t skew;        // start-up skew of every other workgroup, in units of 64 clocks (0 = none)
     const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
 };
 
@@ -492,14 +495,20 @@ struct FftKernel {
     static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t) {
         if constexpr (I < LAST) {
             constexpr int R = Cfg::R(I), C = Cfg::C(I);
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_read<I>(lds, v, t);
             frame_sync();  // everyone has read before anyone overwrites
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
             const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
+            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(1);
             apply_twiddles<I>(v, tw, t);
 #pragma unroll
             for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0>(v + c);
+            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(0);
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_write<I>(lds, v, t);
             frame_sync();
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
             middle_pass<I + 1>(lds, lds_all, v, a, t);
         }
     }
@@ -609,6 +618,12 @@ struct FftKernel {
             u_step = G;
         }
 
+        // De-phase the workgroups that share a CU: they start in lockstep, and as long as
+        // they stay so their VALU phases and their LDS phases coincide instead of overlapping.
+        if (a.skew != 0 && (((b >> 3) ^ (b >> 8)) & 1)) {
+            for (uint32_t i = 0; i < a.skew; i += 16) __builtin_amdgcn_s_sleep(16);
+        }
+
         const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
         const uint32_t esz = elem_bytes(mode);
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
@@ -656,13 +671,18 @@ struct FftKernel {
             load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < u_end ? total_in : 0), in_voff, raw);
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_write<0>(lds, v, t);
             frame_sync();
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
             middle_pass<1>(lds, lds_all, v, a, t);
 
             // last pass
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_read<LAST>(lds, v, t);
             frame_sync();  // the buffer is free for the next frame's pass 0
+            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
+            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(1);
             if constexpr (Cfg::TWR) {
                 if constexpr (PRESCALED) {
 #pragma unroll
@@ -681,6 +701,7 @@ struct FftKernel {
             }
 #pragma unroll
             for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
+            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(0);
             epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
         }
     }

@@ -1,0 +1,165 @@
+/*
+ * easypng.c -- 8-bit gray PNG writer / reader on zlib (include/easypng.h).
+ * Writer: IHDR (8-bit, colour type 0, no interlace), one IDAT of the zlib-compressed
+ * scanlines (filter type 0), IEND; what c/easypng.h:6-53 asks libpng for.
+ * Reader: all five scanline filters, colour types 0/2/4/6 at 8 bits, converted to gray with
+ * stb_image's integer luma (77 r + 150 g + 29 b) >> 8, as c/fft-stitch.c:172 requests.
+ */
+#include "easypng.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+static void put_u32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+
+static uint32_t get_u32(const uint8_t *p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+static int write_chunk(FILE *fp, const char *type, const uint8_t *data, uint32_t len) {
+    uint8_t head[8], tail[4];
+    put_u32(head, len);
+    memcpy(head + 4, type, 4);
+    uLong crc = crc32(0L, head + 4, 4);
+    if (len) crc = crc32(crc, data, len);
+    put_u32(tail, (uint32_t)crc);
+    if (fwrite(head, 1, 8, fp) != 8) return -1;
+    if (len && fwrite(data, 1, len, fp) != len) return -1;
+    if (fwrite(tail, 1, 4, fp) != 4) return -1;
+    return 0;
+}
+
+int write_gray_png(const char *fname, int width, int height, const uint8_t *buffer) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (width <= 0 || height <= 0 || buffer == NULL) {
+        printf("ERROR: invalid image %d x %d.\n", width, height);
+        return -1;
+    }
+    FILE *fp = fopen(fname, "wb");
+    if (!fp) {
+        printf("ERROR: Could not write open file %s for writing.\n", fname);
+        return -1;
+    }
+    const size_t stride = (size_t)width + 1;
+    uint8_t *raw = (uint8_t *)malloc(stride * (size_t)height);
+    uLongf zcap = compressBound((uLong)(stride * (size_t)height));
+    uint8_t *z = (uint8_t *)malloc(zcap);
+    int rc = -1;
+    if (raw && z) {
+        for (int y = 0; y < height; y++) {
+            raw[(size_t)y * stride] = 0; /* filter type: none */
+            memcpy(raw + (size_t)y * stride + 1, buffer + (size_t)y * (size_t)width, (size_t)width);
+        }
+        if (compress2(z, &zcap, raw, (uLong)(stride * (size_t)height), Z_DEFAULT_COMPRESSION) == Z_OK &&
+            zcap <= 0x7fffffffu) {
+            uint8_t ihdr[13];
+            put_u32(ihdr, (uint32_t)width);
+            put_u32(ihdr + 4, (uint32_t)height);
+            ihdr[8] = 8;  /* bit depth */
+            ihdr[9] = 0;  /* gray */
+            ihdr[10] = 0; /* deflate */
+            ihdr[11] = 0; /* adaptive filtering */
+            ihdr[12] = 0; /* no interlace */
+            if (fwrite(sig, 1, 8, fp) == 8 && write_chunk(fp, "IHDR", ihdr, 13) == 0 &&
+                write_chunk(fp, "IDAT", z, (uint32_t)zcap) == 0 && write_chunk(fp, "IEND", NULL, 0) == 0) {
+                rc = 0;
+            }
+        }
+    }
+    free(raw);
+    free(z);
+    if (fclose(fp) != 0) rc = -1;
+    if (rc == 0) {
+        printf("Written %s.\n", fname);
+    } else {
+        printf("ERROR: writing %s failed.\n", fname);
+    }
+    return rc;
+}
+
+static int paeth(int a, int b, int c) {
+    int p = a + b - c;
+    int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+uint8_t *read_gray_png(const char *fname, int *width, int *height) {
+    FILE *fp = fopen(fname, "rb");
+    if (!fp) return NULL;
+    fseek(fp, 0L, SEEK_END);
+    long size = ftell(fp);
+    rewind(fp);
+    uint8_t *file = size > 8 ? (uint8_t *)malloc((size_t)size) : NULL;
+    if (!file || fread(file, 1, (size_t)size, fp) != (size_t)size) {
+        free(file);
+        fclose(fp);
+        return NULL;
+    }
+    fclose(fp);
+    uint8_t *idat = (uint8_t *)malloc((size_t)size);
+    size_t idat_len = 0;
+    uint32_t w = 0, h = 0;
+    int channels = 0, ok = idat != NULL && memcmp(file, "\x89PNG\r\n\x1a\n", 8) == 0;
+    for (size_t pos = 8; ok && pos + 12 <= (size_t)size;) {
+        uint32_t len = get_u32(file + pos);
+        const uint8_t *type = file + pos + 4, *data = file + pos + 8;
+        if (pos + 12 + (size_t)len > (size_t)size) { ok = 0; break; }
+        if (memcmp(type, "IHDR", 4) == 0 && len == 13) {
+            w = get_u32(data);
+            h = get_u32(data + 4);
+            int ct = data[9];
+            channels = ct == 0 ? 1 : ct == 4 ? 2 : ct == 2 ? 3 : ct == 6 ? 4 : 0;
+            if (data[8] != 8 || channels == 0 || data[12] != 0 || w == 0 || h == 0) ok = 0;
+        } else if (memcmp(type, "IDAT", 4) == 0) {
+            memcpy(idat + idat_len, data, len);
+            idat_len += len;
+        } else if (memcmp(type, "IEND", 4) == 0) {
+            break;
+        }
+        pos += 12 + (size_t)len;
+    }
+    uint8_t *out = NULL;
+    if (ok && channels && idat_len) {
+        const size_t bpp = (size_t)channels, stride = (size_t)w * bpp;
+        uLongf raw_len = (uLongf)((stride + 1) * (size_t)h);
+        uint8_t *raw = (uint8_t *)malloc(raw_len);
+        out = (uint8_t *)malloc((size_t)w * (size_t)h);
+        if (raw && out && uncompress(raw, &raw_len, idat, (uLong)idat_len) == Z_OK &&
+            raw_len == (stride + 1) * (size_t)h) {
+            uint8_t *prev = (uint8_t *)calloc(stride, 1);
+            for (uint32_t y = 0; y < h && prev; y++) {
+                uint8_t *line = raw + (size_t)y * (stride + 1);
+                const int ft = line[0];
+                uint8_t *cur = line + 1;
+                for (size_t i = 0; i < stride; i++) {
+                    int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                    int add = ft == 1 ? a : ft == 2 ? b : ft == 3 ? (a + b) / 2 : ft == 4 ? paeth(a, b, c) : 0;
+                    cur[i] = (uint8_t)(cur[i] + add);
+                }
+                for (uint32_t x = 0; x < w; x++) {
+                    const uint8_t *px = cur + (size_t)x * bpp;
+                    out[(size_t)y * w + x] =
+                        channels <= 2 ? px[0] : (uint8_t)((px[0] * 77 + px[1] * 150 + px[2] * 29) >> 8);
+                }
+                memcpy(prev, cur, stride);
+            }
+            free(prev);
+            *width = (int)w;
+            *height = (int)h;
+        } else {
+            free(out);
+            out = NULL;
+        }
+        free(raw);
+    }
+    free(idat);
+    free(file);
+    return out;
+}

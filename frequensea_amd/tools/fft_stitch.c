@@ -1,0 +1,100 @@
+/*
+ * fsea-fft-stitch -- stitch per-frequency FFT tiles into one image (max-composite on the GPU).
+ *
+ * Re-statement of c/fft-stitch.c:160-189,220-224 and c/fft-stitch-broad.c:46-94:
+ *   tile for frequency f is pasted at x = k * WIDTH_STEP with dst = max(dst, src),
+ *   WIDTH_STEP = FFT_SIZE / (SAMPLE_RATE / FREQUENCY_STEP)  (integer division, as the reference),
+ *   IMAGE_WIDTH = FFT_SIZE + FREQUENCY_RANGE * WIDTH_STEP.
+ * The tick marks and TrueType labels of c/fft-stitch.c:191-217 are not drawn.
+ *
+ * usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--dir DIR] [--device D]
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "easypng.h"
+#include "fsea.h"
+
+static void die(const char *what) {
+    fprintf(stderr, "fsea-fft-stitch: %s: %s\n", what, fsea_last_error_string());
+    exit(EXIT_FAILURE);
+}
+
+int main(int argc, char **argv) {
+    int broad = 0, device = 0, rows = -1;
+    double start = -1, end = -1, step = -1;
+    const char *dir = ".";
+    for (int i = 1; i < argc; i++) {
+        if (strcmp(argv[i], "--broad") == 0) broad = 1;
+        else if (strcmp(argv[i], "--start") == 0 && i + 1 < argc) start = atof(argv[++i]);
+        else if (strcmp(argv[i], "--end") == 0 && i + 1 < argc) end = atof(argv[++i]);
+        else if (strcmp(argv[i], "--step") == 0 && i + 1 < argc) step = atof(argv[++i]);
+        else if (strcmp(argv[i], "--rows") == 0 && i + 1 < argc) rows = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--dir") == 0 && i + 1 < argc) dir = argv[++i];
+        else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = atoi(argv[++i]);
+    }
+    if (start < 0 || end < start) {
+        fprintf(stderr, "usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--dir DIR]\n");
+        return EXIT_FAILURE;
+    }
+    const uint32_t fft_size = broad ? 256 : 1024;
+    const uint32_t sample_rate = 5000000;                      /* SAMPLE_RATE */
+    if (step < 0) step = broad ? 5.0 : 2.0;                     /* FREQUENCY_STEP */
+    const uint32_t step_hz = (uint32_t)(step * 1e6 + 0.5);
+    const uint32_t width_step = fft_size / (sample_rate / step_hz);
+    const uint32_t n_tiles = (uint32_t)((end - start) / step + 1e-9) + 1;
+    const uint32_t image_width = fft_size + (n_tiles - 1) * width_step;
+    uint32_t image_height = 0;
+    void *d_image = NULL, *d_tile = NULL;
+    size_t tile_cap = 0;
+
+    for (uint32_t k = 0; k < n_tiles; k++) {
+        const double f = start + k * step;
+        char file_name[512];
+        if (broad) snprintf(file_name, sizeof(file_name), "%s/broad-%.0f.png", dir, f);
+        else snprintf(file_name, sizeof(file_name), "%s/fft-%.4f.png", dir, f);
+        printf("Composing %s...\n", file_name);
+        int w = 0, h = 0;
+        uint8_t *tile = read_gray_png(file_name, &w, &h);
+        if (!tile) {
+            fprintf(stderr, "ERROR: could not load %s\n", file_name);
+            return EXIT_FAILURE;
+        }
+        if (image_height == 0) {
+            image_height = rows > 0 ? (uint32_t)rows : (uint32_t)h;
+            printf("Image size: %u x %u\n", image_width, image_height);
+            if (fsea_device_alloc(device, (size_t)image_width * image_height, &d_image) != 0) die("fsea_device_alloc");
+            uint8_t *zero = (uint8_t *)calloc((size_t)image_width * image_height, 1);
+            if (fsea_copy_to_device(device, d_image, zero, (size_t)image_width * image_height) != 0) die("clear");
+            free(zero);
+        }
+        if ((uint32_t)w != fft_size || (uint32_t)h < image_height) {
+            fprintf(stderr, "ERROR: bad image size %s\n", file_name);
+            return EXIT_FAILURE;
+        }
+        const size_t bytes = (size_t)fft_size * image_height;
+        if (bytes > tile_cap) {
+            fsea_device_free(device, d_tile);
+            if (fsea_device_alloc(device, bytes, &d_tile) != 0) die("fsea_device_alloc");
+            tile_cap = bytes;
+        }
+        if (fsea_copy_to_device(device, d_tile, tile, bytes) != 0) die("fsea_copy_to_device");
+        if (fsea_composite_max_device(d_image, d_tile, k * width_step, 0, fft_size, image_height, image_width,
+                                      fft_size, device, NULL) != 0) {
+            die("fsea_composite_max_device");
+        }
+        free(tile);
+    }
+    uint8_t *image = (uint8_t *)malloc((size_t)image_width * image_height);
+    if (fsea_copy_to_host(device, image, d_image, (size_t)image_width * image_height) != 0) die("fsea_copy_to_host");
+    char out_name[512];
+    if (broad) snprintf(out_name, sizeof(out_name), "%s/broad-stitched-%.0f-%.0f.png", dir, start, end);
+    else snprintf(out_name, sizeof(out_name), "%s/fft-stitched-%.4f-%.4f.png", dir, start, end);
+    printf("Saving %s...\n", out_name);
+    int rc = write_gray_png(out_name, (int)image_width, (int)image_height, image);
+    free(image);
+    fsea_device_free(device, d_tile);
+    fsea_device_free(device, d_image);
+    return rc == 0 ? 0 : EXIT_FAILURE;
+}

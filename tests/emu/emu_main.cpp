@@ -70,6 +70,7 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.hop = hop;
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
+    a.skew = 0;
     const int mt = (specialised && mode == fsea::MODE_MAG && in_kind == fsea::IN_U8) ? 0 : -1;
     const std::string v = variant ? variant : "";
     if (!v.empty()) {

@@ -1,0 +1,85 @@
+"""GPU tier: the sweep tools (frequensea_amd/bin/fsea-fft-batch, fsea-fft-stitch; C on the C ABI)
+against the oracle's restatement of c/fft-batch*.c and c/fft-stitch*.c, PNGs decoded with PIL."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.conftest import ROOT, synth_iq
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(ROOT, "frequensea_amd", "bin")
+TRANSFER = 262144
+
+
+def _capture(path, seed, transfers, zero=False):
+    raw = np.zeros(transfers * TRANSFER, np.uint8) if zero else synth_iq(seed, transfers * TRANSFER)
+    raw.tofile(path)
+    return raw.reshape(transfers, TRANSFER)
+
+
+def _expected_tile(blocks, n, rows, skip, mode):
+    """Row y (newest first) = first n samples of transfer skip + rows - 1 - y (c/fft-batch.c:62-74)."""
+    return np.stack([O.rows(blocks[skip + rows - 1 - y, : 2 * n], 1, n, mode=mode)[0] for y in range(rows)])
+
+
+def _png(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.array(im)
+
+
+def _close(got, want):
+    d = np.abs(got.astype(int) - want.astype(int))
+    return d.max() <= 1 and np.count_nonzero(d) <= max(1, got.size // 1000)
+
+
+def test_broad_sweep_gate_and_stitch(tmp_path):
+    n, rows, skip = 256, 120, 3
+    freqs = [660, 665, 670, 675]
+    caps = {f: _capture(tmp_path / ("c%d.raw" % f), f, rows + skip, zero=(f == 670)) for f in freqs}
+    args = [os.path.join(BIN, "fsea-fft-batch"), "--broad", "--rows", str(rows), "--skip", str(skip),
+            "--out", str(tmp_path)] + ["%d=%s" % (f, tmp_path / ("c%d.raw" % f)) for f in freqs]
+    out = subprocess.run(args, capture_output=True, text=True, check=True).stdout
+    assert "Not interesting. Skipping..." in out          # the all-zero capture: mean |X| = 0.71 < 1.1
+    assert not os.path.exists(tmp_path / "broad-670.png")
+    tiles = {}
+    for f in (660, 665, 675):
+        got = _png(tmp_path / ("broad-%d.png" % f))
+        want = _expected_tile(caps[f], n, rows, skip, O.MODE_DB5_U8_DCFIX)
+        assert got.shape == (rows, n) and _close(got, want)
+        assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
+        tiles[f] = got
+    # stitch 660..665 (two tiles, step 5 MHz at 5 Msps -> WIDTH_STEP = 256, no overlap)
+    subprocess.run([os.path.join(BIN, "fsea-fft-stitch"), "--broad", "--start", "660", "--end", "665",
+                    "--dir", str(tmp_path)], capture_output=True, text=True, check=True)
+    img = _png(tmp_path / "broad-stitched-660-665.png")
+    want = np.zeros((rows, 2 * n), np.uint8)
+    O.composite_max(want, np.ascontiguousarray(tiles[660]), 0)
+    O.composite_max(want, np.ascontiguousarray(tiles[665]), n)
+    assert np.array_equal(img, want)
+
+
+def test_narrow_sweep_overlapping_stitch(tmp_path):
+    n, rows, skip = 1024, 33, 10
+    freqs = [1802.0, 1804.0, 1806.0]
+    caps = [_capture(tmp_path / ("n%d.raw" % i), 50 + i, rows + skip) for i in range(3)]
+    args = [os.path.join(BIN, "fsea-fft-batch"), "--rows", str(rows), "--out", str(tmp_path)]
+    args += ["%.4f=%s" % (f, tmp_path / ("n%d.raw" % i)) for i, f in enumerate(freqs)]
+    subprocess.run(args, capture_output=True, text=True, check=True)
+    tiles = []
+    for i, f in enumerate(freqs):
+        got = _png(tmp_path / ("fft-%.4f.png" % f))
+        assert _close(got, _expected_tile(caps[i], n, rows, skip, O.MODE_DB10_U8))
+        tiles.append(got)
+    subprocess.run([os.path.join(BIN, "fsea-fft-stitch"), "--start", "1802", "--end", "1806", "--dir", str(tmp_path)],
+                   capture_output=True, text=True, check=True)
+    img = _png(tmp_path / "fft-stitched-1802.0000-1806.0000.png")
+    step = 1024 // (5000000 // 2000000)                   # 512: 50 % overlap (c/fft-stitch.c:25)
+    want = np.zeros((rows, 1024 + 2 * step), np.uint8)
+    for k, t in enumerate(tiles):
+        O.composite_max(want, np.ascontiguousarray(t), k * step)
+    assert img.shape == want.shape and np.array_equal(img, want)

@@ -166,3 +166,33 @@ def test_replay_device_missing_file_is_zero_block():
         assert np.all(arr == 0x80)    # int8 0 -> offset-binary 128
     finally:
         L.nrf_device_free(dev)
+
+
+def test_png_writer_and_reader_against_pil(tmp_path):
+    """include/easypng.h: same on-disk format as the reference's libpng writer (8-bit gray,
+    non-interlaced); checked both ways against an independent codec (PIL)."""
+    from PIL import Image
+    L = ctypes.CDLL(nrf.lib_path())
+    L.write_gray_png.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.read_gray_png.restype = ctypes.POINTER(ctypes.c_uint8)
+    L.read_gray_png.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    for shape in ((1, 1), (37, 256), (300, 1024)):
+        img = np.random.default_rng(shape[0]).integers(0, 256, shape, dtype=np.uint8)
+        ours = str(tmp_path / "ours.png").encode()
+        assert L.write_gray_png(ours, shape[1], shape[0], img.ctypes.data) == 0
+        with Image.open(ours.decode()) as im:
+            assert im.mode == "L" and np.array_equal(np.array(im), img)
+        theirs = str(tmp_path / "pil.png")
+        Image.fromarray(img).save(theirs)              # adaptive scanline filters
+        w, h = ctypes.c_int(), ctypes.c_int()
+        p = L.read_gray_png(theirs.encode(), ctypes.byref(w), ctypes.byref(h))
+        assert (h.value, w.value) == shape
+        assert np.array_equal(np.ctypeslib.as_array(p, shape=shape), img)
+    rgb = np.random.default_rng(9).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(str(tmp_path / "rgb.png"))
+    w, h = ctypes.c_int(), ctypes.c_int()
+    p = L.read_gray_png(str(tmp_path / "rgb.png").encode(), ctypes.byref(w), ctypes.byref(h))
+    want = ((rgb[..., 0].astype(int) * 77 + rgb[..., 1].astype(int) * 150 + rgb[..., 2].astype(int) * 29) >> 8)
+    assert np.array_equal(np.ctypeslib.as_array(p, shape=(8, 8)), want.astype(np.uint8))
+    assert not L.read_gray_png(b"/nonexistent.png", ctypes.byref(w), ctypes.byref(h))
+    assert L.write_gray_png(b"/nonexistent-dir/x.png", 4, 4, img.ctypes.data) == -1
