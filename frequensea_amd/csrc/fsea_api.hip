@@ -32,6 +32,8 @@ extern "C" int fsea_kernels_varsmall(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_varmid(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_ablate(fsea::KernelEntry *out, int cap);
 
+#define FSEA_CTR_SLOTS 64u
+
 namespace {
 
 thread_local std::string g_last_error = "";
@@ -184,7 +186,9 @@ struct fsea_plan {
     fsea::cf *d_tw = nullptr;      // passes 1..np-1 concatenated
     size_t tw_off[4] = {0, 0, 0, 0};
     int num_cu = 0;
-    uint32_t skew = 0;
+    unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x {next ticket, finished workers}
+    unsigned launch_seq = 0;
+    unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics
     int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0;
     // staging for the host-buffer entry points
     std::mutex mu;
@@ -233,7 +237,10 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.hop = (size_t)p->hop;
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
-    a.skew = p->skew;
+    // every launch gets its own ticket-counter slot (zero on entry, reset by its last worker), so
+    // launches of one plan may overlap on different streams
+    a.ctr = p->d_ctr + 2 * (p->launch_seq++ % FSEA_CTR_SLOTS);
+    a.trace = p->d_trace;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     const int occ = (in_kind == fsea::IN_F32) ? p->occ_f32 : (mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8);
     p->entry->launch(in_kind, a, grid_for(p, occ, n_frames), s);
@@ -293,7 +300,11 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     p->entry = e;
     p->num_cu = prop.multiProcessorCount;
     p->kernel_name = (mode == FSEA_MODE_MAG_F32) ? e->name_u8_mag : e->name_u8;
-    if (const char *sk = std::getenv("FSEA_SKEW")) p->skew = (uint32_t)std::atoi(sk);  // tuning hook
+    if (std::getenv("FSEA_TRACE")) {
+        if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 2 * sizeof(unsigned long long)) != hipSuccess) {
+            p->d_trace = nullptr;
+        }
+    }
 
     std::vector<fsea::TwPair> tw;
     fsea::build_twiddles(e->np, e->radix, tw, p->tw_off);
@@ -302,6 +313,8 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     if (he == hipSuccess) he = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(fsea::cf), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_acc), sizeof(double));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_ctr), FSEA_CTR_SLOTS * 2 * sizeof(unsigned));
+    if (he == hipSuccess) he = hipMemset(p->d_ctr, 0, FSEA_CTR_SLOTS * 2 * sizeof(unsigned));
     if (he == hipSuccess) he = hipEventCreate(&p->ev0);
     if (he == hipSuccess) he = hipEventCreate(&p->ev1);
     if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8_mag, e->fn_u8_mag, e->wg, 0);
@@ -329,6 +342,8 @@ int fsea_plan_destroy(fsea_plan *p) {
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->d_aux) (void)hipFree(p->d_aux);
     if (p->d_acc) (void)hipFree(p->d_acc);
+    if (p->d_trace) (void)hipFree(p->d_trace);
+    if (p->d_ctr) (void)hipFree(p->d_ctr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -339,6 +354,14 @@ int fsea_plan_destroy(fsea_plan *p) {
 size_t fsea_plan_row_bytes(const fsea_plan *p) { return p ? (size_t)p->n * mode_elem_bytes(p->mode) : 0; }
 int fsea_plan_fft_size(const fsea_plan *p) { return p ? p->n : 0; }
 const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_name.c_str() : ""; }
+
+// Diagnostics (FSEA_TRACE=1): copies the [grid][2] start/end wall-clock ticks of the last launch.
+int fsea_plan_read_trace(fsea_plan *p, unsigned long long *out, unsigned n_workgroups) {
+    if (!p || !p->d_trace || n_workgroups > 4096) return fail(FSEA_EINVAL, "tracing is not enabled for this plan");
+    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_HIP(hipMemcpy(out, p->d_trace, (size_t)n_workgroups * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return FSEA_OK;
+}
 
 int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned *block, size_t *lds_bytes) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");

@@ -167,6 +167,7 @@ struct FftCfg {
         return i <= 1 ? FPW_ * LDS_FRAME : lds_tw_off(i - 1) + tw_len(i - 1);
     }
     static constexpr int LDS_TOTAL = TWL_ ? lds_tw_off(NP_ - 1) : FPW_ * LDS_FRAME;
+    static constexpr int LDS_ALLOC = LDS_TOTAL + 2;  // + two ticket words (dynamic frame distribution)
     static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
     static_assert(N_ % T_ == 0, "T must divide N");
     static_assert(NP_ >= 2 && NP_ <= 4, "2..4 passes");
@@ -179,7 +180,8 @@ struct FftArgs {
     size_t hop;           // samples between frame starts
     uint32_t xormask;     // u8 input: 0 when flip (raw int8), 0x80808080 otherwise
     int mode;             // MODE_*
-    uint32_t skew;        // start-up skew of every other workgroup, in units of 64 clocks (0 = none)
+    unsigned *ctr;        // ticket counter slot of this launch: [0] next ticket, [1] finished workers
+    unsigned long long *trace;  // diagnostics: [grid][2] wall-clock ticks at workgroup start / end, or null
     const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
 };
 
@@ -596,46 +598,57 @@ struct FftKernel {
         }
     }
 
+    // ---- dynamic frame distribution ------------------------------------------------
+    // Workgroups of one launch do not run at the same speed (measured: +-20 % between
+    // CUs, scripts/wg_trace.py), so frames are handed out by an atomic ticket counter
+    // instead of a static split.  A worker is a workgroup -- or, for sizes whose frames
+    // live inside one wavefront (no barrier couples the waves), a single wave.  Its first
+    // unit is static (worker id, no atomic on the start-up path); every later unit is
+    // n_workers + ticket.  Tickets are fetched two iterations ahead so that the atomic's
+    // latency is never waited for.  ctr[0] = next ticket, ctr[1] = finished workers; the
+    // last worker to finish resets both for the next launch on this counter slot.
+    static constexpr bool PER_WAVE = ONE_WAVE;
+    static constexpr int UNIT_FRAMES = PER_WAVE ? (T >= 64 ? 1 : 64 / T) : FPW;
+    static constexpr int WORKERS_PER_WG = PER_WAVE ? (Cfg::WG >= 64 ? Cfg::WG / 64 : 1) : 1;
+
+    static __device__ __forceinline__ unsigned issue_ticket(unsigned *ctr, bool issuer) {
+        unsigned v = 0;
+        if (issuer) v = atomicAdd(ctr, 1u);
+        return v;
+    }
+
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
         const int tid = threadIdx.x;
-        const int slot = (FPW == 1) ? 0 : tid / T;  // FPW == 1: the frame index is wave-uniform
+        const int slot = (FPW == 1) ? 0 : tid / T;  // LDS region of this lane's frame
         const int t = (FPW == 1) ? tid : tid % T;
+        const int fi = PER_WAVE ? ((tid & 63) / T) : slot;  // frame index inside the worker's unit
         cf *lds = lds_all + slot * Cfg::LDS_FRAME;
+        unsigned *tk = reinterpret_cast<unsigned *>(lds_all + Cfg::LDS_TOTAL);  // 2 ticket words (workgroup workers)
 
-        // XCD-aware unit mapping: workgroup b runs on XCD b % 8; give each XCD a
-        // contiguous range of frames so that overlapped (hop < N) frames share L2.
-        const size_t units = (a.n_frames + FPW - 1) / FPW;
-        const unsigned G = gridDim.x, b = blockIdx.x;
-        size_t u, u_end, u_step;
-        if (G >= 8 && (G & 7) == 0) {
-            const unsigned x = b & 7;
-            u = units * x / 8 + (b >> 3);
-            u_end = units * (x + 1) / 8;
-            u_step = G >> 3;
-        } else {
-            u = b;
-            u_end = units;
-            u_step = G;
-        }
+        const unsigned b = blockIdx.x;
+        const unsigned n_workers = gridDim.x * WORKERS_PER_WG;
+        const unsigned worker = PER_WAVE ? b * WORKERS_PER_WG + (unsigned)(tid >> 6) : b;
+        const bool issuer = PER_WAVE ? ((tid & 63) == 0) : (tid == 0);
+        const size_t n_units = (a.n_frames + UNIT_FRAMES - 1) / UNIT_FRAMES;
 
-        // De-phase the workgroups that share a CU: they start in lockstep, and as long as
-        // they stay so their VALU phases and their LDS phases coincide instead of overlapping.
-        if (a.skew != 0 && (((b >> 3) ^ (b >> 8)) & 1)) {
-            for (uint32_t i = 0; i < a.skew; i += 16) __builtin_amdgcn_s_sleep(16);
-        }
+        if (a.trace != nullptr && tid == 0) a.trace[2 * b] = wall_clock64();
 
         const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
         const uint32_t esz = elem_bytes(mode);
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
         const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
-        const uint32_t in_voff = (uint32_t)IN_BPS * ((uint32_t)slot * (uint32_t)a.hop + (uint32_t)(C0 * t));
-        const uint32_t out_elem = (uint32_t)slot * (uint32_t)N + (uint32_t)(CL * t);
+        const uint32_t in_voff = (uint32_t)IN_BPS * ((uint32_t)fi * (uint32_t)a.hop + (uint32_t)(C0 * t));
+        const uint32_t out_elem = (uint32_t)fi * (uint32_t)N + (uint32_t)(CL * t);
 
         // Prologue: every independent request is issued before the first wait, so that
-        // the latencies overlap: unit 0's bytes (HBM starts streaming at once), the
-        // register-resident last-pass twiddles, then the middle-pass tables for LDS.
+        // the latencies overlap: the ticket for the second unit, unit 0's bytes (HBM
+        // starts streaming at once), the register-resident last-pass twiddles, then the
+        // middle-pass tables for LDS.
+        size_t u = worker;
+        unsigned tick_next = issue_ticket(a.ctr, issuer);
         Raw raw[R0];
-        load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < u_end ? total_in : 0), in_voff, raw);
+        load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * UNIT_FRAMES) * a.hop, u < n_units ? total_in : 0), in_voff,
+                 raw);
 
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
         if constexpr (Cfg::TWR) {
@@ -658,23 +671,44 @@ struct FftKernel {
             for (int i = 0; i < (RL - 1) * CL; ++i) twl[i] = twl[i] * cf{SC, SC};
         }
 
-        for (; u < u_end; u += u_step) {
-            const size_t un = u + u_step;
+        unsigned par = 0;
+        while (u < n_units) {
+            // next unit: the ticket requested one iteration ago has long arrived
+            size_t un;
+            if constexpr (PER_WAVE) {
+                un = (size_t)n_workers + __builtin_amdgcn_readfirstlane(tick_next);
+                tick_next = issue_ticket(a.ctr, issuer);
+            } else {
+                if (issuer) {
+                    tk[par] = tick_next;  // published to the workgroup by the barrier after pass 0
+                    tick_next = issue_ticket(a.ctr, true);
+                }
+            }
 
-            // A slot without a frame (ragged last unit) still runs the barriers; it simply
-            // transforms whatever bytes it holds and stores nothing.
+            // A lane without a frame (ragged last unit) still runs the barriers; it simply
+            // transforms the zeros its loads returned and its stores are dropped.
             cf v[P];
 #pragma unroll
             for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
-            // prefetch: the next frame's bytes are requested as soon as this frame's
-            // are converted and stay in flight during the whole transform
-            load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < u_end ? total_in : 0), in_voff, raw);
+            // prefetch: the next unit's bytes are requested as soon as this unit's are
+            // converted (wave workers) or right after the first barrier (workgroup workers,
+            // which learn the ticket there) and stay in flight during the whole transform
+            if constexpr (PER_WAVE) {
+                load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * UNIT_FRAMES) * a.hop, un < n_units ? total_in : 0),
+                         in_voff, raw);
+            }
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
             if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_write<0>(lds, v, t);
             frame_sync();
             if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
+            if constexpr (!PER_WAVE) {
+                un = (size_t)n_workers + __builtin_amdgcn_readfirstlane(tk[par]);
+                par ^= 1u;
+                load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * UNIT_FRAMES) * a.hop, un < n_units ? total_in : 0),
+                         in_voff, raw);
+            }
             middle_pass<1>(lds, lds_all, v, a, t);
 
             // last pass
@@ -702,8 +736,21 @@ struct FftKernel {
 #pragma unroll
             for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
             if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(0);
-            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * UNIT_FRAMES) * (size_t)N, total_out), out_elem, v, t);
+            u = un;
         }
+
+        // this worker is done: its outstanding ticket request must have landed before it is
+        // counted, so that the last worker's reset cannot be overtaken by a late increment
+        if (issuer) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned finished = atomicAdd(a.ctr + 1, 1u);
+            if (finished == n_workers - 1) {
+                a.ctr[0] = 0;
+                a.ctr[1] = 0;
+            }
+        }
+        if (a.trace != nullptr && tid == 0) a.trace[2 * b + 1] = wall_clock64();
     }
 };
 

@@ -36,17 +36,17 @@ struct KernelEntry {
     using NAME##_cfg = fsea::FftCfg<__VA_ARGS__>;                                                     \
     extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_u8(          \
         fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_TOTAL];                    \
+        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
         fsea::FftKernel<NAME##_cfg, fsea::IN_U8>::run(a, lds);                                        \
     }                                                                                                 \
     extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_u8_mag(      \
         fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_TOTAL];                    \
+        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
         fsea::FftKernel<NAME##_cfg, fsea::IN_U8, fsea::MODE_MAG>::run(a, lds);                        \
     }                                                                                                 \
     extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_f32(         \
         fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_TOTAL];                    \
+        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
         fsea::FftKernel<NAME##_cfg, fsea::IN_F32>::run(a, lds);                                       \
     }                                                                                                 \
     static void NAME##_launch(int in_kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {    \
@@ -67,7 +67,7 @@ struct KernelEntry {
         NAME##_cfg::WG,                                                                               \
         NAME##_cfg::NP,                                                                               \
         {NAME##_cfg::R(0), NAME##_cfg::R(1), NAME##_cfg::R(2), NAME##_cfg::R(3)},                     \
-        sizeof(fsea::cf) * NAME##_cfg::LDS_TOTAL,                                                       \
+        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC,                                                       \
         NAME##_cfg::C(0),                                                                             \
         reinterpret_cast<const void *>(&NAME##_u8_mag),                                               \
         reinterpret_cast<const void *>(&NAME##_u8),                                                   \

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostics: when do the workgroups of one launch start and finish? (FSEA_TRACE=1)"""
+import ctypes, os, sys
+import numpy as np
+os.environ["FSEA_TRACE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from frequensea_amd import fsea
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+L = fsea.hip_lib()
+L.fsea_plan_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+def dev_alloc(nbytes):
+    p = ctypes.c_void_p(); fsea._check(L.fsea_device_alloc(0, nbytes, ctypes.byref(p))); return p
+sets = 8
+d_in = [dev_alloc(2 * n * frames) for _ in range(sets)]
+d_out = [dev_alloc(4 * n * frames) for _ in range(sets)]
+host = np.random.default_rng(1).integers(-70, 70, 2 * n * frames, dtype=np.int8).view(np.uint8)
+for d in d_in:
+    fsea._check(L.fsea_copy_to_device(0, d, host.ctypes.data, host.nbytes))
+plan = fsea.Plan(n)
+grid = plan.grid(frames)[0]
+for k in range(200):                      # warm clocks, rotate buffers
+    plan.exec_device(d_in[k % sets], frames, d_out[k % sets])
+plan.synchronize()
+ms = plan.time_device(d_in[0], frames, d_out[0], 1)
+tr = np.zeros((grid, 2), dtype=np.uint64)
+fsea._check(L.fsea_plan_read_trace(plan._p, tr.ctypes.data, grid))
+t = (tr.astype(np.int64) - int(tr[:, 0].min())) / 100.0      # wall_clock64 ticks at 100 MHz -> us
+st, en = t[:, 0], t[:, 1]
+print("N=%d frames=%d grid=%d  event time %.1f us" % (n, frames, grid, ms * 1e3))
+print("start: min %.2f  p50 %.2f  p99 %.2f  max %.2f us" % (st.min(), np.median(st), np.percentile(st, 99), st.max()))
+print("end  : min %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max()))
+dur = en - st
+print("workgroup duration: min %.2f  p50 %.2f  max %.2f us;  mean %.2f" % (dur.min(), np.median(dur), dur.max(), dur.mean()))
+print("idle tail if perfectly balanced: %.2f us (max end - mean end)" % (en.max() - en.mean()))

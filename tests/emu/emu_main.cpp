@@ -1,7 +1,9 @@
 // TEST-ONLY: runs the real kernel body (fsea_fft_core.h) on the CPU, see hip/hip_runtime.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <barrier>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -14,7 +16,17 @@
 
 thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 static thread_local std::barrier<> *g_barrier = nullptr;
+static thread_local std::barrier<> *g_wave_barrier = nullptr;
+static thread_local unsigned *g_wave_slot = nullptr;  // one word per wave for readfirstlane
 void emu_syncthreads() { g_barrier->arrive_and_wait(); }
+void emu_wave_barrier() { g_wave_barrier->arrive_and_wait(); }
+unsigned emu_readfirstlane(unsigned v) {
+    if ((threadIdx.x & 63) == 0) *g_wave_slot = v;
+    g_wave_barrier->arrive_and_wait();
+    const unsigned r = *g_wave_slot;
+    g_wave_barrier->arrive_and_wait();
+    return r;
+}
 
 template <class Cfg, int IN, int MODE_T>
 static void run_grid(fsea::FftArgs a, unsigned grid) {
@@ -23,11 +35,19 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
     const int radix[4] = {Cfg::R(0), Cfg::R(1), Cfg::R(2), Cfg::R(3)};
     fsea::build_twiddles(Cfg::NP, radix, tw, off);
     for (int i = 0; i < 4; ++i) a.tw[i] = reinterpret_cast<const fsea::cf *>(tw.data()) + off[i];
+    unsigned ctr[2] = {0, 0};
+    a.ctr = ctr;
     for (unsigned b = 0; b < grid; ++b) {
-        std::vector<fsea::cf> lds_store(Cfg::LDS_TOTAL + 2);
+        std::vector<fsea::cf> lds_store(Cfg::LDS_ALLOC + 2);
         fsea::cf *lds = lds_store.data();
         if (reinterpret_cast<uintptr_t>(lds) & 15) lds += 1;  // 16-byte alignment as on the device
         std::barrier<> bar(Cfg::WG);
+        constexpr int WAVES = (Cfg::WG + 63) / 64;
+        std::vector<std::unique_ptr<std::barrier<>>> wbar;
+        std::vector<unsigned> wslot(WAVES, 0);
+        for (int w = 0; w < WAVES; ++w) {
+            wbar.emplace_back(new std::barrier<>(std::min(64, Cfg::WG - 64 * w)));
+        }
         std::vector<std::thread> th;
         for (int t = 0; t < Cfg::WG; ++t) {
             th.emplace_back([&, t] {
@@ -36,11 +56,15 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
                 blockDim.x = Cfg::WG;
                 gridDim.x = grid;
                 g_barrier = &bar;
+                g_wave_barrier = wbar[t / 64].get();
+                g_wave_slot = &wslot[t / 64];
                 fsea::FftKernel<Cfg, IN, MODE_T>::run(a, lds);
             });
         }
         for (auto &x : th) x.join();
     }
+    // the last worker of the launch must have reset the ticket counter for the next launch
+    if (ctr[0] != 0 || ctr[1] != 0) std::abort();
 }
 
 template <class Cfg>
@@ -70,7 +94,7 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.hop = hop;
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
-    a.skew = 0;
+    a.trace = nullptr;
     const int mt = (specialised && mode == fsea::MODE_MAG && in_kind == fsea::IN_U8) ? 0 : -1;
     const std::string v = variant ? variant : "";
     if (!v.empty()) {

@@ -26,9 +26,14 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 struct emu_dim3 { unsigned x = 1, y = 1, z = 1; };
 extern thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
-void emu_syncthreads();
+void emu_syncthreads();   // all work-items of the emulated workgroup
+void emu_wave_barrier();  // the 64 work-items of this work-item's wavefront
+unsigned emu_readfirstlane(unsigned v);
 #define __syncthreads() emu_syncthreads()
-#define __builtin_amdgcn_wave_barrier() emu_syncthreads()
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
+#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
+#define __builtin_amdgcn_s_waitcnt(n) ((void)0)
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 // clang vector builtins used by the packed-math code, for g++ vector_size types
 template <class V>
@@ -84,6 +89,7 @@ static inline void emu_bs128(emu_u32x4 d, emu_rsrc rs, uint32_t v, uint32_t s, i
 #define __builtin_amdgcn_raw_buffer_store_b32(...) emu_bs32(__VA_ARGS__)
 #define __builtin_amdgcn_raw_buffer_store_b64(...) emu_bs64(__VA_ARGS__)
 #define __builtin_amdgcn_raw_buffer_store_b128(...) emu_bs128(__VA_ARGS__)
+static inline unsigned long long wall_clock64() { return 0; }
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
