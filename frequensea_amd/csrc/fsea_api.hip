@@ -33,6 +33,7 @@ extern "C" int fsea_kernels_varmid(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_ablate(fsea::KernelEntry *out, int cap);
 
 #define FSEA_CTR_SLOTS 64u
+#define FSEA_CTR_WORDS (9u * 32u)  // 8 ticket pools + the finished-workgroups word, one 128-byte line each
 
 namespace {
 
@@ -186,7 +187,7 @@ struct fsea_plan {
     fsea::cf *d_tw = nullptr;      // passes 1..np-1 concatenated
     size_t tw_off[4] = {0, 0, 0, 0};
     int num_cu = 0;
-    unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x {next ticket, finished workers}
+    unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x FSEA_CTR_WORDS ticket counters
     unsigned launch_seq = 0;
     unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics
     int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0;
@@ -239,7 +240,7 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.mode = mode;
     // every launch gets its own ticket-counter slot (zero on entry, reset by its last worker), so
     // launches of one plan may overlap on different streams
-    a.ctr = p->d_ctr + 2 * (p->launch_seq++ % FSEA_CTR_SLOTS);
+    a.ctr = p->d_ctr + FSEA_CTR_WORDS * (p->launch_seq++ % FSEA_CTR_SLOTS);
     a.trace = p->d_trace;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     const int occ = (in_kind == fsea::IN_F32) ? p->occ_f32 : (mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8);
@@ -313,8 +314,8 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     if (he == hipSuccess) he = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(fsea::cf), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_acc), sizeof(double));
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_ctr), FSEA_CTR_SLOTS * 2 * sizeof(unsigned));
-    if (he == hipSuccess) he = hipMemset(p->d_ctr, 0, FSEA_CTR_SLOTS * 2 * sizeof(unsigned));
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_ctr), FSEA_CTR_SLOTS * FSEA_CTR_WORDS * sizeof(unsigned));
+    if (he == hipSuccess) he = hipMemset(p->d_ctr, 0, FSEA_CTR_SLOTS * FSEA_CTR_WORDS * sizeof(unsigned));
     if (he == hipSuccess) he = hipEventCreate(&p->ev0);
     if (he == hipSuccess) he = hipEventCreate(&p->ev1);
     if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8_mag, e->fn_u8_mag, e->wg, 0);

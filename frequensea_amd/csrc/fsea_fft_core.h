@@ -180,7 +180,7 @@ struct FftArgs {
     size_t hop;           // samples between frame starts
     uint32_t xormask;     // u8 input: 0 when flip (raw int8), 0x80808080 otherwise
     int mode;             // MODE_*
-    unsigned *ctr;        // ticket counter slot of this launch: [0] next ticket, [1] finished workers
+    unsigned *ctr;        // ticket-counter slot of this launch: [32 q] pool q, [32 * 8] finished workgroups
     unsigned long long *trace;  // diagnostics: [grid][2] wall-clock ticks at workgroup start / end, or null
     const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
 };
@@ -599,37 +599,45 @@ struct FftKernel {
     }
 
     // ---- dynamic frame distribution ------------------------------------------------
-    // Workgroups of one launch do not run at the same speed (measured: +-20 % between
-    // CUs, scripts/wg_trace.py), so frames are handed out by an atomic ticket counter
-    // instead of a static split.  A worker is a workgroup -- or, for sizes whose frames
-    // live inside one wavefront (no barrier couples the waves), a single wave.  Its first
-    // unit is static (worker id, no atomic on the start-up path); every later unit is
-    // n_workers + ticket.  Tickets are fetched two iterations ahead so that the atomic's
-    // latency is never waited for.  ctr[0] = next ticket, ctr[1] = finished workers; the
-    // last worker to finish resets both for the next launch on this counter slot.
-    static constexpr bool PER_WAVE = ONE_WAVE;
-    static constexpr int UNIT_FRAMES = PER_WAVE ? (T >= 64 ? 1 : 64 / T) : FPW;
-    static constexpr int WORKERS_PER_WG = PER_WAVE ? (Cfg::WG >= 64 ? Cfg::WG / 64 : 1) : 1;
+    // Workgroups of one launch do not run at the same speed (measured: the slowest takes
+    // 1.5x the fastest, scripts/wg_trace.py), so units (FPW frames) are handed out by
+    // atomic ticket counters instead of a static split.  One counter saturates near 90
+    // tickets/us on this chip, so there are POOLS of them: the units are cut into POOLS
+    // contiguous ranges, a workgroup draws from its home pool (blockIdx % POOLS, which is
+    // also its XCD) and steals from the other pools when that one runs dry.  The first
+    // unit of a workgroup is static (no atomic on the start-up path) and tickets are
+    // requested two iterations ahead, so the atomic's latency is only ever waited for
+    // when stealing at the very end of a launch.  Counter words sit in separate 128-byte
+    // lines: ctr[32 q] = tickets drawn from pool q, ctr[32 POOLS] = finished workgroups;
+    // the last workgroup to finish zeroes them for the next launch on this slot.
+    static constexpr unsigned POOLS = 8;
+    static constexpr unsigned NO_UNIT = 0xffffffffu;
 
-    static __device__ __forceinline__ unsigned issue_ticket(unsigned *ctr, bool issuer) {
-        unsigned v = 0;
-        if (issuer) v = atomicAdd(ctr, 1u);
-        return v;
-    }
+    struct Pools {
+        unsigned n_units, grid;
+        __device__ __forceinline__ unsigned start(unsigned q) const { return (unsigned)((size_t)n_units * q / POOLS); }
+        __device__ __forceinline__ unsigned homed(unsigned q) const { return (grid + POOLS - 1 - q) / POOLS; }
+        // unit for ticket t of pool q, or NO_UNIT when the pool is exhausted
+        __device__ __forceinline__ unsigned unit(unsigned q, unsigned t) const {
+            const unsigned long long idx = (unsigned long long)start(q) + homed(q) + t;
+            return idx < start(q + 1) ? (unsigned)idx : NO_UNIT;
+        }
+    };
 
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
         const int tid = threadIdx.x;
-        const int slot = (FPW == 1) ? 0 : tid / T;  // LDS region of this lane's frame
+        const int slot = (FPW == 1) ? 0 : tid / T;  // frame index inside the unit = LDS region
         const int t = (FPW == 1) ? tid : tid % T;
-        const int fi = PER_WAVE ? ((tid & 63) / T) : slot;  // frame index inside the worker's unit
         cf *lds = lds_all + slot * Cfg::LDS_FRAME;
-        unsigned *tk = reinterpret_cast<unsigned *>(lds_all + Cfg::LDS_TOTAL);  // 2 ticket words (workgroup workers)
+        unsigned *tk = reinterpret_cast<unsigned *>(lds_all + Cfg::LDS_TOTAL);  // 2 words: next unit, ping-pong
 
         const unsigned b = blockIdx.x;
-        const unsigned n_workers = gridDim.x * WORKERS_PER_WG;
-        const unsigned worker = PER_WAVE ? b * WORKERS_PER_WG + (unsigned)(tid >> 6) : b;
-        const bool issuer = PER_WAVE ? ((tid & 63) == 0) : (tid == 0);
-        const size_t n_units = (a.n_frames + UNIT_FRAMES - 1) / UNIT_FRAMES;
+        const bool issuer = (tid == 0);
+        const size_t n_units = (a.n_frames + FPW - 1) / FPW;
+        Pools pools;
+        pools.n_units = (unsigned)n_units;
+        pools.grid = gridDim.x;
+        unsigned cur = b % POOLS;  // pool this workgroup is drawing from (issuer lane only)
 
         if (a.trace != nullptr && tid == 0) a.trace[2 * b] = wall_clock64();
 
@@ -637,18 +645,19 @@ struct FftKernel {
         const uint32_t esz = elem_bytes(mode);
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
         const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
-        const uint32_t in_voff = (uint32_t)IN_BPS * ((uint32_t)fi * (uint32_t)a.hop + (uint32_t)(C0 * t));
-        const uint32_t out_elem = (uint32_t)fi * (uint32_t)N + (uint32_t)(CL * t);
+        const uint32_t in_voff = (uint32_t)IN_BPS * ((uint32_t)slot * (uint32_t)a.hop + (uint32_t)(C0 * t));
+        const uint32_t out_elem = (uint32_t)slot * (uint32_t)N + (uint32_t)(CL * t);
 
         // Prologue: every independent request is issued before the first wait, so that
         // the latencies overlap: the ticket for the second unit, unit 0's bytes (HBM
         // starts streaming at once), the register-resident last-pass twiddles, then the
         // middle-pass tables for LDS.
-        size_t u = worker;
-        unsigned tick_next = issue_ticket(a.ctr, issuer);
+        size_t u = (size_t)pools.start(cur) + b / POOLS;  // static first unit
+        if (u >= pools.start(cur + 1)) u = n_units;        // more workgroups than units in this pool
+        unsigned tick_next = 0;
+        if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
         Raw raw[R0];
-        load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * UNIT_FRAMES) * a.hop, u < n_units ? total_in : 0), in_voff,
-                 raw);
+        load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
 
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
         if constexpr (Cfg::TWR) {
@@ -671,18 +680,41 @@ struct FftKernel {
             for (int i = 0; i < (RL - 1) * CL; ++i) twl[i] = twl[i] * cf{SC, SC};
         }
 
+        // A workgroup whose static unit does not exist still has to look for work (another
+        // pool may be long): resolve its first ticket synchronously.
         unsigned par = 0;
-        while (u < n_units) {
-            // next unit: the ticket requested one iteration ago has long arrived
-            size_t un;
-            if constexpr (PER_WAVE) {
-                un = (size_t)n_workers + __builtin_amdgcn_readfirstlane(tick_next);
-                tick_next = issue_ticket(a.ctr, issuer);
-            } else {
-                if (issuer) {
-                    tk[par] = tick_next;  // published to the workgroup by the barrier after pass 0
-                    tick_next = issue_ticket(a.ctr, true);
+        if (u >= n_units) {
+            if (issuer) {
+                unsigned nu = pools.unit(cur, tick_next);
+                for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
+                    const unsigned q = (cur + k) % POOLS;
+                    nu = pools.unit(q, atomicAdd(a.ctr + 32 * q, 1u));
+                    if (nu != NO_UNIT) cur = q;
                 }
+                tk[0] = nu;
+                tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+            }
+            __syncthreads();
+            const unsigned nu = __builtin_amdgcn_readfirstlane(tk[0]);
+            __syncthreads();
+            u = (nu == NO_UNIT) ? n_units : (size_t)nu;
+            load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+        }
+
+        while (u < n_units) {
+            // Next unit: the ticket requested one iteration ago has long arrived.  If the
+            // pool it came from is exhausted, steal from the others (synchronous; this only
+            // happens at the end of a launch).  Published to the workgroup by the first
+            // barrier of this iteration.
+            if (issuer) {
+                unsigned nu = pools.unit(cur, tick_next);
+                for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
+                    const unsigned q = (cur + k) % POOLS;
+                    nu = pools.unit(q, atomicAdd(a.ctr + 32 * q, 1u));
+                    if (nu != NO_UNIT) cur = q;
+                }
+                tk[par] = nu;
+                tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
             }
 
             // A lane without a frame (ragged last unit) still runs the barriers; it simply
@@ -690,25 +722,19 @@ struct FftKernel {
             cf v[P];
 #pragma unroll
             for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
-            // prefetch: the next unit's bytes are requested as soon as this unit's are
-            // converted (wave workers) or right after the first barrier (workgroup workers,
-            // which learn the ticket there) and stay in flight during the whole transform
-            if constexpr (PER_WAVE) {
-                load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * UNIT_FRAMES) * a.hop, un < n_units ? total_in : 0),
-                         in_voff, raw);
-            }
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
             if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_write<0>(lds, v, t);
             frame_sync();
             if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
-            if constexpr (!PER_WAVE) {
-                un = (size_t)n_workers + __builtin_amdgcn_readfirstlane(tk[par]);
-                par ^= 1u;
-                load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * UNIT_FRAMES) * a.hop, un < n_units ? total_in : 0),
-                         in_voff, raw);
-            }
+            // prefetch: the next unit is known to every lane now; its bytes stay in flight
+            // during the rest of the transform
+            if constexpr (ONE_WAVE && Cfg::WG > 64) __syncthreads();  // single-wave frames: publish tk
+            const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
+            par ^= 1u;
+            const size_t un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+            load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
             middle_pass<1>(lds, lds_all, v, a, t);
 
             // last pass
@@ -736,7 +762,7 @@ struct FftKernel {
 #pragma unroll
             for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
             if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(0);
-            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * UNIT_FRAMES) * (size_t)N, total_out), out_elem, v, t);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
             u = un;
         }
 
@@ -744,10 +770,10 @@ struct FftKernel {
         // counted, so that the last worker's reset cannot be overtaken by a late increment
         if (issuer) {
             __builtin_amdgcn_s_waitcnt(0);
-            const unsigned finished = atomicAdd(a.ctr + 1, 1u);
-            if (finished == n_workers - 1) {
-                a.ctr[0] = 0;
-                a.ctr[1] = 0;
+            const unsigned finished = atomicAdd(a.ctr + 32 * POOLS, 1u);
+            if (finished == gridDim.x - 1) {
+#pragma unroll
+                for (unsigned q = 0; q <= POOLS; ++q) a.ctr[32 * q] = 0;
             }
         }
         if (a.trace != nullptr && tid == 0) a.trace[2 * b + 1] = wall_clock64();

@@ -35,8 +35,8 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
     const int radix[4] = {Cfg::R(0), Cfg::R(1), Cfg::R(2), Cfg::R(3)};
     fsea::build_twiddles(Cfg::NP, radix, tw, off);
     for (int i = 0; i < 4; ++i) a.tw[i] = reinterpret_cast<const fsea::cf *>(tw.data()) + off[i];
-    unsigned ctr[2] = {0, 0};
-    a.ctr = ctr;
+    std::vector<unsigned> ctr(9 * 32, 0u);
+    a.ctr = ctr.data();
     for (unsigned b = 0; b < grid; ++b) {
         std::vector<fsea::cf> lds_store(Cfg::LDS_ALLOC + 2);
         fsea::cf *lds = lds_store.data();
@@ -64,7 +64,9 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
         for (auto &x : th) x.join();
     }
     // the last worker of the launch must have reset the ticket counter for the next launch
-    if (ctr[0] != 0 || ctr[1] != 0) std::abort();
+    for (unsigned c : ctr) {
+        if (c != 0) std::abort();
+    }
 }
 
 template <class Cfg>
