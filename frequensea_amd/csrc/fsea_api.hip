@@ -302,7 +302,7 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     p->num_cu = prop.multiProcessorCount;
     p->kernel_name = (mode == FSEA_MODE_MAG_F32) ? e->name_u8_mag : e->name_u8;
     if (std::getenv("FSEA_TRACE")) {
-        if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 2 * sizeof(unsigned long long)) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 8 * sizeof(unsigned long long)) != hipSuccess) {
             p->d_trace = nullptr;
         }
     }
@@ -356,11 +356,11 @@ size_t fsea_plan_row_bytes(const fsea_plan *p) { return p ? (size_t)p->n * mode_
 int fsea_plan_fft_size(const fsea_plan *p) { return p ? p->n : 0; }
 const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_name.c_str() : ""; }
 
-// Diagnostics (FSEA_TRACE=1): copies the [grid][2] start/end wall-clock ticks of the last launch.
+// Diagnostics (FSEA_TRACE=1): copies the [grid][8] trace words of the last launch.
 int fsea_plan_read_trace(fsea_plan *p, unsigned long long *out, unsigned n_workgroups) {
     if (!p || !p->d_trace || n_workgroups > 4096) return fail(FSEA_EINVAL, "tracing is not enabled for this plan");
     FSEA_HIP(hipSetDevice(p->device));
-    FSEA_HIP(hipMemcpy(out, p->d_trace, (size_t)n_workgroups * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    FSEA_HIP(hipMemcpy(out, p->d_trace, (size_t)n_workgroups * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FSEA_OK;
 }
 

@@ -181,7 +181,7 @@ struct FftArgs {
     uint32_t xormask;     // u8 input: 0 when flip (raw int8), 0x80808080 otherwise
     int mode;             // MODE_*
     unsigned *ctr;        // ticket-counter slot of this launch: [32 q] pool q, [32 * 8] finished workgroups
-    unsigned long long *trace;  // diagnostics: [grid][2] wall-clock ticks at workgroup start / end, or null
+    unsigned long long *trace;  // diagnostics: [grid][8] = wall start/end, shader-clock start/end, HW_ID, XCC_ID; or null
     const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
 };
 
@@ -639,7 +639,15 @@ struct FftKernel {
         pools.grid = gridDim.x;
         unsigned cur = b % POOLS;  // pool this workgroup is drawing from (issuer lane only)
 
-        if (a.trace != nullptr && tid == 0) a.trace[2 * b] = wall_clock64();
+        if (a.trace != nullptr && tid == 0) {
+            unsigned hw_id, xcc_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            a.trace[8 * b + 0] = wall_clock64();
+            a.trace[8 * b + 2] = __builtin_readcyclecounter();
+            a.trace[8 * b + 4] = hw_id;
+            a.trace[8 * b + 5] = xcc_id;
+        }
 
         const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
         const uint32_t esz = elem_bytes(mode);
@@ -776,7 +784,10 @@ struct FftKernel {
                 for (unsigned q = 0; q <= POOLS; ++q) a.ctr[32 * q] = 0;
             }
         }
-        if (a.trace != nullptr && tid == 0) a.trace[2 * b + 1] = wall_clock64();
+        if (a.trace != nullptr && tid == 0) {
+            a.trace[8 * b + 1] = wall_clock64();
+            a.trace[8 * b + 3] = __builtin_readcyclecounter();
+        }
     }
 };
 

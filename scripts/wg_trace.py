@@ -25,13 +25,29 @@ for k in range(200):                      # warm clocks, rotate buffers
     plan.exec_device(d_in[k % sets], frames, d_out[k % sets])
 plan.synchronize()
 ms = plan.time_device(d_in[0], frames, d_out[0], 1)
-tr = np.zeros((grid, 2), dtype=np.uint64)
+tr = np.zeros((grid, 8), dtype=np.uint64)
 fsea._check(L.fsea_plan_read_trace(plan._p, tr.ctypes.data, grid))
-t = (tr.astype(np.int64) - int(tr[:, 0].min())) / 100.0      # wall_clock64 ticks at 100 MHz -> us
+t = (tr[:, :2].astype(np.int64) - int(tr[:, 0].min())) / 100.0      # wall_clock64 ticks at 100 MHz -> us
 st, en = t[:, 0], t[:, 1]
+clk = (tr[:, 3].astype(np.int64) - tr[:, 2].astype(np.int64)) / np.maximum(en - st, 1e-9) / 1e3   # GHz
+hw = tr[:, 4].astype(np.int64)
+xcc = tr[:, 5].astype(np.int64) & 0xf
+cu = (hw >> 8) & 0xf
+sh = (hw >> 12) & 0x1
+se = (hw >> 13) & 0x7
 print("N=%d frames=%d grid=%d  event time %.1f us" % (n, frames, grid, ms * 1e3))
 print("start: min %.2f  p50 %.2f  p99 %.2f  max %.2f us" % (st.min(), np.median(st), np.percentile(st, 99), st.max()))
 print("end  : min %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max()))
 dur = en - st
 print("workgroup duration: min %.2f  p50 %.2f  max %.2f us;  mean %.2f" % (dur.min(), np.median(dur), dur.max(), dur.mean()))
 print("idle tail if perfectly balanced: %.2f us (max end - mean end)" % (en.max() - en.mean()))
+print("shader clock seen by workgroups: min %.3f  mean %.3f  max %.3f GHz" % (clk.min(), clk.mean(), clk.max()))
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print("  XCC %d: %3d workgroups, mean duration %.2f us, clock %.3f GHz, distinct (se,sh,cu) %d"
+              % (x, m.sum(), dur[m].mean(), clk[m].mean(), len(set(zip(se[m], sh[m], cu[m])))))
+key = xcc * 1000 + se * 100 + sh * 10 * 2 + cu
+import collections
+cnt = collections.Counter(zip(xcc, se, sh, cu))
+print("workgroups per physical CU: " + str(sorted(collections.Counter(cnt.values()).items())))
