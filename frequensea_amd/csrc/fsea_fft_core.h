@@ -640,9 +640,7 @@ struct FftKernel {
         unsigned cur = b % POOLS;  // pool this workgroup is drawing from (issuer lane only)
 
         if (a.trace != nullptr && tid == 0) {
-            unsigned hw_id, xcc_id;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+            const unsigned hw_id = read_hw_id(), xcc_id = read_xcc_id();
             a.trace[8 * b + 0] = wall_clock64();
             a.trace[8 * b + 2] = __builtin_readcyclecounter();
             a.trace[8 * b + 4] = hw_id;

@@ -22,4 +22,16 @@ __device__ __forceinline__ cf pk_cmul(cf a, cf w) {
     return t;
 }
 
+// Diagnostics only (FSEA_TRACE): where a workgroup runs.
+__device__ __forceinline__ unsigned read_hw_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    return v;
+}
+__device__ __forceinline__ unsigned read_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v;
+}
+
 }  // namespace fsea

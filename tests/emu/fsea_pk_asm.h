@@ -13,4 +13,7 @@ static inline cf pk_cmul(cf a, cf w) {
     return t;
 }
 
+static inline unsigned read_hw_id() { return 0; }
+static inline unsigned read_xcc_id() { return 0; }
+
 }  // namespace fsea
