@@ -132,6 +132,37 @@ def test_device_resident_and_ragged_counts():
     plan.close()
 
 
+def test_repeated_launches_reset_their_ticket_counters():
+    """Frames are handed out by atomic ticket counters that the last workgroup of a launch resets;
+    a stale counter would make a later launch skip frames.  Launch the same plan many times with
+    changing frame counts (more than the 64 counter slots) and check every row each time."""
+    n = 1024
+    plan = fsea.Plan(n)
+    nf_max = 5000
+    iq = synth_iq(77, 2 * nf_max * n)
+    want = O.rows(iq, 64, n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_out = DeviceBuffer(nf_max * n * 4)
+    rng = np.random.default_rng(0)
+    for it in range(150):
+        nf = int(rng.integers(1, nf_max))
+        d_out.upload(np.full(min(nf, 64) * n, -1.0, np.float32))      # poison what will be checked
+        plan.exec_device(d_in.ptr, nf, d_out.ptr)
+        plan.synchronize()
+        k = min(nf, 64)
+        got = d_out.download(np.float32, (k, n))
+        assert got.min() >= 0.0, "launch %d (nf=%d) left rows unwritten" % (it, nf)
+        parity.check_float(got, want[:k])
+    # last rows of a big launch too
+    plan.exec_device(d_in.ptr, nf_max, d_out.ptr)
+    plan.synchronize()
+    got = d_out.download(np.float32, (nf_max, n))[-8:]
+    parity.check_float(got, O.rows(iq[2 * n * (nf_max - 8):], 8, n))
+    d_in.free()
+    d_out.free()
+    plan.close()
+
+
 def test_f64_input_branch():
     n, nf = 1024, 7
     rng = np.random.default_rng(3)
