@@ -26,7 +26,7 @@ EXPORTS = [
     "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_mean_magnitude_u8_device",
     "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
     "fsea_copy_to_host", "fsea_stream_synchronize", "fsea_time_exec_u8_device",
-    "fsea_plan_kernel_name", "fsea_last_error_string",
+    "fsea_plan_kernel_name", "fsea_last_error_string", "fsea_plan_read_trace",
 ]
 
 

@@ -37,6 +37,15 @@ def test_nrf_exports_every_declared_symbol():
             assert hasattr(L, name), name
 
 
+def test_easypng_exports():
+    L = ctypes.CDLL(nrf.lib_path())
+    text = open(os.path.join(ROOT, "include", "easypng.h")).read()
+    names = set(re.findall(r"\b((?:write|read)_gray_png)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+    assert names == {"write_gray_png", "read_gray_png"}
+    for name in names:
+        assert hasattr(L, name)
+
+
 def test_no_gpu_fails_loudly_without_fallback():
     if fsea.device_count() > 0:
         pytest.skip("a GPU is present")
