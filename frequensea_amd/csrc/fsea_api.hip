@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -188,7 +189,7 @@ struct fsea_plan {
     size_t tw_off[4] = {0, 0, 0, 0};
     int num_cu = 0;
     unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x FSEA_CTR_WORDS ticket counters
-    unsigned launch_seq = 0;
+    std::atomic<unsigned> launch_seq{0};
     unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics
     int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0;
     // staging for the host-buffer entry points
@@ -240,7 +241,7 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.mode = mode;
     // every launch gets its own ticket-counter slot (zero on entry, reset by its last worker), so
     // launches of one plan may overlap on different streams
-    a.ctr = p->d_ctr + FSEA_CTR_WORDS * (p->launch_seq++ % FSEA_CTR_SLOTS);
+    a.ctr = p->d_ctr + FSEA_CTR_WORDS * (p->launch_seq.fetch_add(1) % FSEA_CTR_SLOTS);
     a.trace = p->d_trace;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     const int occ = (in_kind == fsea::IN_F32) ? p->occ_f32 : (mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8);

@@ -38,7 +38,8 @@ nrf_fft *nrf_fft_new(int fft_size, int fft_history_size) {
     fft->fft_size = fft_size;
     fft->fft_history_size = fft_history_size;
     fsea_plan *plan = NULL;
-    int rc = fsea_plan_create(&plan, fft_size, fft_size, FSEA_MODE_MAG_F32, 0);
+    const char *dev_env = getenv("NRF_FFT_DEVICE"); /* which GPU; the reference has no such notion */
+    int rc = fsea_plan_create(&plan, fft_size, fft_size, FSEA_MODE_MAG_F32, dev_env ? atoi(dev_env) : 0);
     if (rc != FSEA_OK) fsea_fatal("fsea_plan_create", rc);
     fft->backend = plan;
     fft->buffer = (double *)calloc((size_t)fft_size * (size_t)fft_history_size, sizeof(double));
