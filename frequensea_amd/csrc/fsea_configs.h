@@ -37,5 +37,3 @@
 #define FSEA_CFG_8192_B_NOFLOP 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4
 #define FSEA_CFG_8192_B_IO 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6
 #define FSEA_CFG_8192_B_VALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 3
-#define FSEA_CFG_8192_PRIOLDS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 8
-#define FSEA_CFG_8192_PRIOVALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 16

@@ -146,8 +146,6 @@ enum : int { IN_U8 = 0, IN_F32 = 1 };
 template <int N_, int T_, int FPW_, int WPE_, int NP_, int R0_, int R1_, int R2_ = 1, int R3_ = 1,
           bool TWL_ = true, bool TWR_ = true, int ABL_ = 0>
 struct FftCfg {
-    // ABL bits 8 / 16 are scheduling experiments, not ablations: raise the wave priority
-    // (s_setprio 1) around the LDS phases (8) or around the butterfly phases (16).
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
     static constexpr int ABL = ABL_;
@@ -497,20 +495,14 @@ struct FftKernel {
     static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t) {
         if constexpr (I < LAST) {
             constexpr int R = Cfg::R(I), C = Cfg::C(I);
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_read<I>(lds, v, t);
             frame_sync();  // everyone has read before anyone overwrites
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
             const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
-            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(1);
             apply_twiddles<I>(v, tw, t);
 #pragma unroll
             for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0>(v + c);
-            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(0);
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_write<I>(lds, v, t);
             frame_sync();
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
             middle_pass<I + 1>(lds, lds_all, v, a, t);
         }
     }
@@ -730,10 +722,8 @@ struct FftKernel {
             for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_write<0>(lds, v, t);
             frame_sync();
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
             if constexpr (ONE_WAVE && Cfg::WG > 64) __syncthreads();  // single-wave frames: publish tk
@@ -744,11 +734,8 @@ struct FftKernel {
             middle_pass<1>(lds, lds_all, v, a, t);
 
             // last pass
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(1);
             lds_read<LAST>(lds, v, t);
             frame_sync();  // the buffer is free for the next frame's pass 0
-            if constexpr (Cfg::ABL & 8) __builtin_amdgcn_s_setprio(0);
-            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(1);
             if constexpr (Cfg::TWR) {
                 if constexpr (PRESCALED) {
 #pragma unroll
@@ -767,7 +754,6 @@ struct FftKernel {
             }
 #pragma unroll
             for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
-            if constexpr (Cfg::ABL & 16) __builtin_amdgcn_s_setprio(0);
             epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
             u = un;
         }

@@ -6,8 +6,6 @@ FSEA_DEFINE_KERNEL(fsea_abl8192_nolds, "abl_nolds", FSEA_CFG_8192_B_NOLDS)
 FSEA_DEFINE_KERNEL(fsea_abl8192_noflop, "abl_noflop", FSEA_CFG_8192_B_NOFLOP)
 FSEA_DEFINE_KERNEL(fsea_abl8192_io, "abl_io", FSEA_CFG_8192_B_IO)
 FSEA_DEFINE_KERNEL(fsea_abl8192_valu, "abl_valu", FSEA_CFG_8192_B_VALU)
-FSEA_DEFINE_KERNEL(fsea_exp8192_priolds, "prio_lds", FSEA_CFG_8192_PRIOLDS)
-FSEA_DEFINE_KERNEL(fsea_exp8192_priovalu, "prio_valu", FSEA_CFG_8192_PRIOVALU)
 extern "C" int fsea_kernels_ablate(fsea::KernelEntry *out, int cap) {
     int n = 0;
     if (n < cap) out[n++] = fsea_abl8192_nostore_entry();
@@ -15,7 +13,5 @@ extern "C" int fsea_kernels_ablate(fsea::KernelEntry *out, int cap) {
     if (n < cap) out[n++] = fsea_abl8192_noflop_entry();
     if (n < cap) out[n++] = fsea_abl8192_io_entry();
     if (n < cap) out[n++] = fsea_abl8192_valu_entry();
-    if (n < cap) out[n++] = fsea_exp8192_priolds_entry();
-    if (n < cap) out[n++] = fsea_exp8192_priovalu_entry();
     return n;
 }

@@ -15,7 +15,7 @@ from oracle import oracle as O  # noqa: E402
 
 VARIANTS = {
     8192: ["", "A", "B", "D", "E", "F", "notwl", "notwr",
-           "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu", "prio_lds", "prio_valu"],
+           "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu"],
     1024: ["", "B", "C", "D"],
     4096: ["", "B", "C", "D"],
     128: [""], 256: [""], 512: [""], 2048: ["", "B", "C"], 16384: ["", "B"],
