@@ -186,7 +186,7 @@ struct fsea_plan {
     const fsea::KernelEntry *entry = nullptr;
     hipStream_t stream = nullptr;
     fsea::cf *d_tw = nullptr;      // passes 1..np-1 concatenated
-    size_t tw_off[4] = {0, 0, 0, 0};
+    size_t tw_off[5] = {0, 0, 0, 0, 0};  // passes 0..3, then the HI/LO factor tables (fsea_tables.h)
     int num_cu = 0;
     unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x FSEA_CTR_WORDS ticket counters
     std::atomic<unsigned> launch_seq{0};
@@ -244,6 +244,7 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.ctr = p->d_ctr + FSEA_CTR_WORDS * (p->launch_seq.fetch_add(1) % FSEA_CTR_SLOTS);
     a.trace = p->d_trace;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
+    a.tw_small = p->d_tw;
     const int occ = (in_kind == fsea::IN_F32) ? p->occ_f32 : (mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8);
     p->entry->launch(in_kind, a, grid_for(p, occ, n_frames), s);
     FSEA_HIP(hipGetLastError());
@@ -303,7 +304,7 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     p->num_cu = prop.multiProcessorCount;
     p->kernel_name = (mode == FSEA_MODE_MAG_F32) ? e->name_u8_mag : e->name_u8;
     if (std::getenv("FSEA_TRACE")) {
-        if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 8 * sizeof(unsigned long long)) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 32 * sizeof(unsigned long long)) != hipSuccess) {
             p->d_trace = nullptr;
         }
     }
@@ -357,11 +358,11 @@ size_t fsea_plan_row_bytes(const fsea_plan *p) { return p ? (size_t)p->n * mode_
 int fsea_plan_fft_size(const fsea_plan *p) { return p ? p->n : 0; }
 const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_name.c_str() : ""; }
 
-// Diagnostics (FSEA_TRACE=1): copies the [grid][8] trace words of the last launch.
+// Diagnostics (FSEA_TRACE=1): copies the [grid][32] trace words of the last launch.
 int fsea_plan_read_trace(fsea_plan *p, unsigned long long *out, unsigned n_workgroups) {
     if (!p || !p->d_trace || n_workgroups > 4096) return fail(FSEA_EINVAL, "tracing is not enabled for this plan");
     FSEA_HIP(hipSetDevice(p->device));
-    FSEA_HIP(hipMemcpy(out, p->d_trace, (size_t)n_workgroups * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    FSEA_HIP(hipMemcpy(out, p->d_trace, (size_t)n_workgroups * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FSEA_OK;
 }
 

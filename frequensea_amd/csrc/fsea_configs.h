@@ -18,8 +18,6 @@
 #define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true
 #define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
 #define FSEA_CFG_8192_D 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true
-#define FSEA_CFG_8192_E 8192, 512, 1, 4, 4, 16, 16, 8, 4, false, true
-#define FSEA_CFG_8192_F 8192, 512, 1, 4, 4, 8, 16, 16, 4, false, true
 #define FSEA_CFG_8192_NOTWL 8192, 256, 1, 2, 3, 16, 32, 16, 1, false, true
 #define FSEA_CFG_8192_NOTWR 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, false
 #define FSEA_CFG_1024_B 1024, 64, 4, 4, 3, 16, 16, 4, 1, true, true

@@ -164,7 +164,14 @@ struct FftCfg {
     static constexpr int lds_tw_off(int i) {
         return i <= 1 ? FPW_ * LDS_FRAME : lds_tw_off(i - 1) + tw_len(i - 1);
     }
-    static constexpr int LDS_TOTAL = TWL_ ? lds_tw_off(NP_ - 1) : FPW_ * LDS_FRAME;
+    // small twiddle block kept in LDS: middle-pass tables, then the two factor tables
+    // HI[N/64] = W^{64 h}, LO[64] = W^{l} the last pass's register twiddles are built from
+    static constexpr int TAB_MID = lds_tw_off(NP_ - 1) - FPW_ * LDS_FRAME;
+    static constexpr int TAB_HI = N_ / 64, TAB_LO = 64;
+    static constexpr int TAB_SMALL = TAB_MID + (TWR_ ? TAB_HI + TAB_LO : 0);
+    static constexpr int LDS_HI = FPW_ * LDS_FRAME + TAB_MID;
+    static constexpr int LDS_LO = LDS_HI + TAB_HI;
+    static constexpr int LDS_TOTAL = FPW_ * LDS_FRAME + ((TWL_ || TWR_) ? TAB_SMALL : 0);
     static constexpr int LDS_ALLOC = LDS_TOTAL + 2;  // + two ticket words (dynamic frame distribution)
     static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
     static_assert(N_ % T_ == 0, "T must divide N");
@@ -179,8 +186,9 @@ struct FftArgs {
     uint32_t xormask;     // u8 input: 0 when flip (raw int8), 0x80808080 otherwise
     int mode;             // MODE_*
     unsigned *ctr;        // ticket-counter slot of this launch: [32 q] pool q, [32 * 8] finished workgroups
-    unsigned long long *trace;  // diagnostics: [grid][8] = wall start/end, shader-clock start/end, HW_ID, XCC_ID; or null
+    unsigned long long *trace;  // diagnostics: [grid][32] = wall start/end, shader-clock start/end, HW_ID, XCC_ID, -, -, end of iteration 0..23; or null
     const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
+    const cf *tw_small;   // [middle-pass tables | HI | LO], the block copied to LDS (fsea_tables.h)
 };
 
 // ---------------------------------------------------------------------------
@@ -633,10 +641,10 @@ struct FftKernel {
 
         if (a.trace != nullptr && tid == 0) {
             const unsigned hw_id = read_hw_id(), xcc_id = read_xcc_id();
-            a.trace[8 * b + 0] = wall_clock64();
-            a.trace[8 * b + 2] = __builtin_readcyclecounter();
-            a.trace[8 * b + 4] = hw_id;
-            a.trace[8 * b + 5] = xcc_id;
+            a.trace[32 * b + 0] = wall_clock64();
+            a.trace[32 * b + 2] = __builtin_readcyclecounter();
+            a.trace[32 * b + 4] = hw_id;
+            a.trace[32 * b + 5] = xcc_id;
         }
 
         const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
@@ -657,26 +665,19 @@ struct FftKernel {
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
 
+        // the small twiddle block (middle-pass tables + HI/LO factors) is only requested here;
+        // it is written to LDS inside the first iteration, after pass 0, so that neither its
+        // latency nor the start-up burst of every workgroup asking for the same lines is waited
+        // for before the first frame's own work
+        constexpr int TAB_COPY = (Cfg::TWL || Cfg::TWR) ? Cfg::TAB_SMALL : 0;
+        constexpr int TAB_PER_LANE = (TAB_COPY + Cfg::WG - 1) / Cfg::WG;
+        cf tabv[TAB_PER_LANE > 0 ? TAB_PER_LANE : 1];
+#pragma unroll
+        for (int i = 0; i < TAB_PER_LANE; ++i) {
+            const int e = tid + i * Cfg::WG;
+            tabv[i] = (e < TAB_COPY) ? a.tw_small[e] : cf{0.f, 0.f};
+        }
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
-        if constexpr (Cfg::TWR) {
-#pragma unroll
-            for (int r = 1; r < RL; ++r) ld_c<CL>(a.tw[LAST] + (r - 1) * NsL + CL * t, twl + (r - 1) * CL);
-        }
-
-        if constexpr (Cfg::TWL && NP > 2) {
-            constexpr int TOT = Cfg::LDS_TOTAL - FPW * Cfg::LDS_FRAME;
-            cf *dst = lds_all + FPW * Cfg::LDS_FRAME;
-            for (int i = tid; i < TOT; i += Cfg::WG) {
-                // tables of passes 1..LAST-1 are contiguous in the global image too
-                dst[i] = a.tw[1][i];
-            }
-            __syncthreads();
-        }
-
-        if constexpr (PRESCALED) {
-#pragma unroll
-            for (int i = 0; i < (RL - 1) * CL; ++i) twl[i] = twl[i] * cf{SC, SC};
-        }
 
         // A workgroup whose static unit does not exist still has to look for work (another
         // pool may be long): resolve its first ticket synchronously.
@@ -699,6 +700,8 @@ struct FftKernel {
             load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
         }
 
+        unsigned iter = 0;
+        if (a.trace != nullptr && tid == 0) a.trace[32 * b + 6] = wall_clock64();  // prologue done
         while (u < n_units) {
             // Next unit: the ticket requested one iteration ago has long arrived.  If the
             // pool it came from is exhausted, steal from the others (synchronous; this only
@@ -723,10 +726,35 @@ struct FftKernel {
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
             lds_write<0>(lds, v, t);
+            if (iter == 0) {  // first iteration only: the barrier(s) below also publish the small twiddle block
+#pragma unroll
+                for (int i = 0; i < TAB_PER_LANE; ++i) {
+                    const int e = tid + i * Cfg::WG;
+                    if (e < TAB_COPY) lds_all[FPW * Cfg::LDS_FRAME + e] = tabv[i];
+                }
+            }
             frame_sync();
+            if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
+            if constexpr (ONE_WAVE && Cfg::WG > 64) __syncthreads();  // single-wave frames: publish tk
+            if constexpr (Cfg::TWR) {
+                if (iter == 0) {
+                    // last-pass twiddles W^{r k}, k = CL t + c, built once per workgroup from the two
+                    // factor tables: W^{m} = HI[m >> 6] * LO[m & 63]; they stay in registers
+                    const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
+#pragma unroll
+                    for (int r = 1; r < RL; ++r) {
+#pragma unroll
+                        for (int c = 0; c < CL; ++c) {
+                            const unsigned m = (unsigned)r * (unsigned)(CL * t + c);
+                            cf w = pk_cmul(hi[m >> 6], lo[m & 63u]);
+                            if constexpr (PRESCALED) w = w * cf{SC, SC};
+                            twl[(r - 1) * CL + c] = w;
+                        }
+                    }
+                }
+            }
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
-            if constexpr (ONE_WAVE && Cfg::WG > 64) __syncthreads();  // single-wave frames: publish tk
             const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
             par ^= 1u;
             const size_t un = (nu == NO_UNIT) ? n_units : (size_t)nu;
@@ -756,6 +784,8 @@ struct FftKernel {
             for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
             epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
             u = un;
+            if (a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * b + 8 + iter] = wall_clock64();
+            ++iter;
         }
 
         // this worker is done: its outstanding ticket request must have landed before it is
@@ -769,8 +799,8 @@ struct FftKernel {
             }
         }
         if (a.trace != nullptr && tid == 0) {
-            a.trace[8 * b + 1] = wall_clock64();
-            a.trace[8 * b + 3] = __builtin_readcyclecounter();
+            a.trace[32 * b + 1] = wall_clock64();
+            a.trace[32 * b + 3] = __builtin_readcyclecounter();
         }
     }
 };

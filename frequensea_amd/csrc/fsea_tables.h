@@ -1,9 +1,7 @@
 // fsea_tables.h -- host-side twiddle tables for the Stockham passes.
 // Pass i >= 1 uses W^{r k} with W = exp(-2 pi i / (Ns_i R_i)), stored as
-// [(r-1) * Ns_i + k], r = 1..R_i-1, k = 0..Ns_i-1; passes are concatenated in
-// order (pass 1 first), which is also the order the kernel copies the middle
-// passes into LDS.  Angles are reduced exactly in integers and evaluated in
-// double before rounding to f32.
+// [(r-1) * Ns_i + k], r = 1..R_i-1, k = 0..Ns_i-1.  Angles are reduced exactly in
+// integers and evaluated in double before rounding to f32.
 #pragma once
 
 #include <cmath>
@@ -16,23 +14,42 @@ struct TwPair {
     float re, im;
 };
 
+// Image layout (complex f32 entries):
+//   [ pass 1 | ... | pass LAST-1 | HI | LO | pass LAST ]
+// The part before "pass LAST" is the small block a workgroup copies into LDS: the middle-pass
+// tables and the two factors of the last pass, W_N^{64 h} (HI, N/64 entries) and W_N^{l}
+// (LO, 64 entries), from which the kernel builds its register-resident last-pass twiddles as
+// W_N^{m} = HI[m >> 6] * LO[m & 63].  The full last-pass table follows for the configurations
+// that read it from memory every frame.  offsets[i] = start of pass i, offsets[4] = start of HI.
 inline void build_twiddles(int np, const int *radix, std::vector<TwPair> &tw, size_t *offsets) {
     const double two_pi = 6.283185307179586476925286766559;
-    long long ns = radix[0];
+    long long n = 1;
+    for (int i = 0; i < np; ++i) n *= radix[i];
     tw.clear();
-    offsets[0] = 0;
-    for (int i = 1; i < np; ++i) {
+    auto pass_table = [&](int i) {
+        long long ns = 1;
+        for (int k = 0; k < i; ++k) ns *= radix[k];
+        const long long r_i = radix[i], len = ns * r_i;
         offsets[i] = tw.size();
-        const long long r_i = radix[i];
-        const long long len = ns * r_i;
         for (long long r = 1; r < r_i; ++r) {
             for (long long k = 0; k < ns; ++k) {
                 const double ang = -two_pi * (double)((r * k) % len) / (double)len;
                 tw.push_back(TwPair{(float)std::cos(ang), (float)std::sin(ang)});
             }
         }
-        ns *= r_i;
+    };
+    offsets[0] = 0;
+    for (int i = 1; i < np - 1; ++i) pass_table(i);
+    offsets[4] = tw.size();
+    for (long long h = 0; h < n / 64; ++h) {
+        const double ang = -two_pi * (double)(64 * h) / (double)n;
+        tw.push_back(TwPair{(float)std::cos(ang), (float)std::sin(ang)});
     }
+    for (long long l = 0; l < 64; ++l) {
+        const double ang = -two_pi * (double)l / (double)n;
+        tw.push_back(TwPair{(float)std::cos(ang), (float)std::sin(ang)});
+    }
+    pass_table(np - 1);
     for (int i = np; i < 4; ++i) offsets[i] = tw.size();
 }
 

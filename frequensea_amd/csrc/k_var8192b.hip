@@ -1,14 +1,10 @@
-// Tuning variants of the 8192-point kernel (512 lanes, 4 passes; twiddle sources).
+// Tuning variants of the 8192-point kernel (twiddle sources).
 #include "fsea_configs.h"
 #include "fsea_registry.h"
-FSEA_DEFINE_KERNEL(fsea_fft8192E, "E", FSEA_CFG_8192_E)
-FSEA_DEFINE_KERNEL(fsea_fft8192F, "F", FSEA_CFG_8192_F)
 FSEA_DEFINE_KERNEL(fsea_fft8192notwl, "notwl", FSEA_CFG_8192_NOTWL)
 FSEA_DEFINE_KERNEL(fsea_fft8192notwr, "notwr", FSEA_CFG_8192_NOTWR)
 extern "C" int fsea_kernels_var8192b(fsea::KernelEntry *out, int cap) {
     int n = 0;
-    if (n < cap) out[n++] = fsea_fft8192E_entry();
-    if (n < cap) out[n++] = fsea_fft8192F_entry();
     if (n < cap) out[n++] = fsea_fft8192notwl_entry();
     if (n < cap) out[n++] = fsea_fft8192notwr_entry();
     return n;

@@ -145,7 +145,8 @@ int fsea_time_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
 
 /* Diagnostics: when the environment variable FSEA_TRACE is set at plan creation, every launch
  * records per workgroup {wall-clock start, end (100 MHz ticks), shader-clock start, end, HW_ID,
- * XCC_ID, 0, 0}; this copies the [n_workgroups][8] words of the last launch (scripts/wg_trace.py). */
+ * XCC_ID, 0, 0, end of iteration 0..23}; this copies the [n_workgroups][32] words of the last
+ * launch (scripts/wg_trace.py). */
 int fsea_plan_read_trace(fsea_plan *plan, unsigned long long *out, unsigned n_workgroups);
 
 /* Name of the kernel variant the plan launches (for matching rocprof rows). */

@@ -14,7 +14,7 @@ from frequensea_amd import fsea  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 VARIANTS = {
-    8192: ["", "A", "B", "D", "E", "F", "notwl", "notwr",
+    8192: ["", "A", "B", "D", "notwl", "notwr",
            "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu"],
     1024: ["", "B", "C", "D"],
     4096: ["", "B", "C", "D"],

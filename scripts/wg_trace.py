@@ -25,7 +25,7 @@ for k in range(200):                      # warm clocks, rotate buffers
     plan.exec_device(d_in[k % sets], frames, d_out[k % sets])
 plan.synchronize()
 ms = plan.time_device(d_in[0], frames, d_out[0], 1)
-tr = np.zeros((grid, 8), dtype=np.uint64)
+tr = np.zeros((grid, 32), dtype=np.uint64)
 fsea._check(L.fsea_plan_read_trace(plan._p, tr.ctypes.data, grid))
 t = (tr[:, :2].astype(np.int64) - int(tr[:, 0].min())) / 100.0      # wall_clock64 ticks at 100 MHz -> us
 st, en = t[:, 0], t[:, 1]
@@ -51,3 +51,12 @@ key = xcc * 1000 + se * 100 + sh * 10 * 2 + cu
 import collections
 cnt = collections.Counter(zip(xcc, se, sh, cu))
 print("workgroups per physical CU: " + str(sorted(collections.Counter(cnt.values()).items())))
+its = (tr[:, 8:32].astype(np.int64) - tr[:, 0:1].astype(np.int64)) / 100.0
+valid = tr[:, 8:32] != 0
+prev = np.concatenate([np.zeros((grid, 1)), its[:, :-1]], axis=1)
+per = np.where(valid, its - prev, np.nan)
+print("mean time of iteration k (us): " + " ".join("%.2f" % x for x in np.nanmean(per, axis=0)[:min(24, int(valid.sum(axis=1).max()))]))
+pro = (tr[:, 6].astype(np.int64) - tr[:, 0].astype(np.int64)) / 100.0
+p0 = (tr[:, 7].astype(np.int64) - tr[:, 0].astype(np.int64)) / 100.0
+print("prologue done after %.2f us (mean), first pass 0 + barrier after %.2f us, first iteration ends after %.2f us"
+      % (pro.mean(), p0.mean(), np.nanmean(its[:, 0])))

@@ -31,10 +31,11 @@ unsigned emu_readfirstlane(unsigned v) {
 template <class Cfg, int IN, int MODE_T>
 static void run_grid(fsea::FftArgs a, unsigned grid) {
     std::vector<fsea::TwPair> tw;
-    size_t off[4];
+    size_t off[5];
     const int radix[4] = {Cfg::R(0), Cfg::R(1), Cfg::R(2), Cfg::R(3)};
     fsea::build_twiddles(Cfg::NP, radix, tw, off);
     for (int i = 0; i < 4; ++i) a.tw[i] = reinterpret_cast<const fsea::cf *>(tw.data()) + off[i];
+    a.tw_small = reinterpret_cast<const fsea::cf *>(tw.data());
     std::vector<unsigned> ctr(9 * 32, 0u);
     a.ctr = ctr.data();
     for (unsigned b = 0; b < grid; ++b) {
@@ -105,8 +106,6 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
         EMU_VARIANT(8192, "A", FSEA_CFG_8192_A)
         EMU_VARIANT(8192, "B", FSEA_CFG_8192_B)
         EMU_VARIANT(8192, "D", FSEA_CFG_8192_D)
-        EMU_VARIANT(8192, "E", FSEA_CFG_8192_E)
-        EMU_VARIANT(8192, "F", FSEA_CFG_8192_F)
         EMU_VARIANT(8192, "notwl", FSEA_CFG_8192_NOTWL)
         EMU_VARIANT(8192, "notwr", FSEA_CFG_8192_NOTWR)
         EMU_VARIANT(1024, "B", FSEA_CFG_1024_B)
