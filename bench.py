@@ -118,7 +118,7 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
     # Informational only (never `value`): the same steps issued alternately on two streams, so that
     # one launch's drain overlaps the next one's ramp -- what a double-buffered consumer would see.
     two_stream = None
-    if world == 1 and not args.no_extra:
+    if world == 1 and args.two_stream:
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         torch.cuda.synchronize()
         for k in range(max(8, warmup)):
@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--two-stream", action="store_true",
+                    help="also time the steps issued alternately on two streams (informational, in `extra`)")
     ap.add_argument("--cpu-budget", type=float, default=16.0, help="core-seconds for the CPU sample")
     args = ap.parse_args()
 
