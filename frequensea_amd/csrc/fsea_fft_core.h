@@ -665,19 +665,30 @@ struct FftKernel {
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
 
-        // the small twiddle block (middle-pass tables + HI/LO factors) is only requested here;
-        // it is written to LDS inside the first iteration, after pass 0, so that neither its
-        // latency nor the start-up burst of every workgroup asking for the same lines is waited
-        // for before the first frame's own work
+        // The small twiddle block (middle-pass tables + HI/LO factors, a few KiB) goes to LDS, and
+        // the last pass's register-resident twiddles W^{r k}, k = CL t + c, are built from the
+        // two factor tables: W^{m} = HI[m >> 6] * LO[m & 63].  (Loading those (RL-1) CL twiddles
+        // per lane from the full table instead cost 32 MB of L2 traffic per launch and a
+        // 5.8 us prologue.)  All of it overlaps the latency of unit 0's bytes requested above.
         constexpr int TAB_COPY = (Cfg::TWL || Cfg::TWR) ? Cfg::TAB_SMALL : 0;
-        constexpr int TAB_PER_LANE = (TAB_COPY + Cfg::WG - 1) / Cfg::WG;
-        cf tabv[TAB_PER_LANE > 0 ? TAB_PER_LANE : 1];
-#pragma unroll
-        for (int i = 0; i < TAB_PER_LANE; ++i) {
-            const int e = tid + i * Cfg::WG;
-            tabv[i] = (e < TAB_COPY) ? a.tw_small[e] : cf{0.f, 0.f};
+        if constexpr (TAB_COPY > 0) {
+            for (int e = tid; e < TAB_COPY; e += Cfg::WG) lds_all[FPW * Cfg::LDS_FRAME + e] = a.tw_small[e];
+            __syncthreads();
         }
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
+        if constexpr (Cfg::TWR) {
+            const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
+#pragma unroll
+            for (int r = 1; r < RL; ++r) {
+#pragma unroll
+                for (int c = 0; c < CL; ++c) {
+                    const unsigned m = (unsigned)r * (unsigned)(CL * t + c);
+                    cf w = pk_cmul(hi[m >> 6], lo[m & 63u]);
+                    if constexpr (PRESCALED) w = w * cf{SC, SC};
+                    twl[(r - 1) * CL + c] = w;
+                }
+            }
+        }
 
         // A workgroup whose static unit does not exist still has to look for work (another
         // pool may be long): resolve its first ticket synchronously.
@@ -726,33 +737,9 @@ struct FftKernel {
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
             lds_write<0>(lds, v, t);
-            if (iter == 0) {  // first iteration only: the barrier(s) below also publish the small twiddle block
-#pragma unroll
-                for (int i = 0; i < TAB_PER_LANE; ++i) {
-                    const int e = tid + i * Cfg::WG;
-                    if (e < TAB_COPY) lds_all[FPW * Cfg::LDS_FRAME + e] = tabv[i];
-                }
-            }
             frame_sync();
             if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
             if constexpr (ONE_WAVE && Cfg::WG > 64) __syncthreads();  // single-wave frames: publish tk
-            if constexpr (Cfg::TWR) {
-                if (iter == 0) {
-                    // last-pass twiddles W^{r k}, k = CL t + c, built once per workgroup from the two
-                    // factor tables: W^{m} = HI[m >> 6] * LO[m & 63]; they stay in registers
-                    const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
-#pragma unroll
-                    for (int r = 1; r < RL; ++r) {
-#pragma unroll
-                        for (int c = 0; c < CL; ++c) {
-                            const unsigned m = (unsigned)r * (unsigned)(CL * t + c);
-                            cf w = pk_cmul(hi[m >> 6], lo[m & 63u]);
-                            if constexpr (PRESCALED) w = w * cf{SC, SC};
-                            twl[(r - 1) * CL + c] = w;
-                        }
-                    }
-                }
-            }
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
             const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);

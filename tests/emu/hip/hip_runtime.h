@@ -92,5 +92,6 @@ static inline void emu_bs128(emu_u32x4 d, emu_rsrc rs, uint32_t v, uint32_t s, i
 static inline unsigned long long wall_clock64() { return 0; }
 #define __builtin_readcyclecounter() 0ull
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_sched_barrier(n) ((void)0)
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_logf(x) log2f(x)
