@@ -739,7 +739,7 @@ struct FftKernel {
             lds_write<0>(lds, v, t);
             frame_sync();
             if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
-            if constexpr (ONE_WAVE && Cfg::WG > 64) __syncthreads();  // single-wave frames: publish tk
+            if constexpr ((ONE_WAVE && Cfg::WG > 64) || (Cfg::ABL & 2)) __syncthreads();  // publish tk
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
             const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
