@@ -242,17 +242,18 @@ __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uin
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 
 // C consecutive f32 / u8 / complex outputs at byte offset voff (+ scalar soff)
-template <int C>
+// AUX: cache-policy bits of the buffer instruction (0 = default, 2 = nt: streaming, do not keep)
+template <int C, int AUX = 0>
 __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, const float *v) {
     if constexpr (C == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(f2u(v[0]), rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(f2u(v[0]), rs, voff, soff, AUX);
     } else if constexpr (C == 2) {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0]), f2u(v[1])}, rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0]), f2u(v[1])}, rs, voff, soff, AUX);
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c]), f2u(v[c + 1]), f2u(v[c + 2]), f2u(v[c + 3])}, rs,
-                                                   voff + 4 * c, soff, 0);
+                                                   voff + 4 * c, soff, AUX);
         }
     }
 }

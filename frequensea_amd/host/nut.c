@@ -16,10 +16,10 @@
 #include <string.h>
 #include <time.h>
 
-void nut_sleep_milliseconds(int millis) {
+void nut_sleep_milliseconds(int duration_ms) {
     struct timespec ts;
-    ts.tv_sec = millis / 1000;
-    ts.tv_nsec = (long)(millis % 1000) * 1000000L;
+    ts.tv_sec = duration_ms / 1000;
+    ts.tv_nsec = (long)(duration_ms % 1000) * 1000000L;
     nanosleep(&ts, NULL);
 }
 
@@ -61,114 +61,109 @@ static nut_buffer *nut_alloc(nut_buffer_type type, int length, int channels, con
     return b;
 }
 
-nut_buffer *nut_buffer_new_u8(int length, int channels, const uint8_t *data) {
-    return nut_alloc(NUT_BUFFER_U8, length, channels, data);
+nut_buffer *nut_buffer_new_u8(int n_elements, int n_channels, const uint8_t *initial) {
+    return nut_alloc(NUT_BUFFER_U8, n_elements, n_channels, initial);
 }
 
-nut_buffer *nut_buffer_new_f64(int length, int channels, const double *data) {
-    return nut_alloc(NUT_BUFFER_F64, length, channels, data);
+nut_buffer *nut_buffer_new_f64(int n_elements, int n_channels, const double *initial) {
+    return nut_alloc(NUT_BUFFER_F64, n_elements, n_channels, initial);
 }
 
-nut_buffer *nut_buffer_copy(nut_buffer *buffer) {
-    assert(buffer != NULL);
-    return nut_alloc(buffer->type, buffer->length, buffer->channels, payload(buffer));
+nut_buffer *nut_buffer_copy(nut_buffer *source) {
+    assert(source != NULL);
+    return nut_alloc(source->type, source->length, source->channels, payload(source));
 }
 
-nut_buffer *nut_buffer_reduce(nut_buffer *buffer, double percentage) {
-    assert(buffer != NULL);
-    if (percentage < 0.0) percentage = 0.0;
-    if (percentage > 1.0) percentage = 1.0;
-    int keep = (int)round(buffer->length * percentage);
-    return nut_alloc(buffer->type, keep, buffer->channels, payload(buffer));
+nut_buffer *nut_buffer_reduce(nut_buffer *source, double fraction) {
+    assert(source != NULL);
+    const double f = fraction < 0.0 ? 0.0 : (fraction > 1.0 ? 1.0 : fraction);
+    return nut_alloc(source->type, (int)round(source->length * f), source->channels, payload(source));
 }
 
-nut_buffer *nut_buffer_clip(nut_buffer *buffer, int offset, int length) {
-    assert(buffer != NULL);
-    assert((length < 0) || ((buffer->length - offset) >= length));
-    int keep = length;
-    if (keep < 0 || keep > buffer->length - offset) keep = buffer->length - offset;
-    /* the reference offsets the data pointer by `offset` elements, not frames */
-    const uint8_t *from = (const uint8_t *)payload(buffer) + (size_t)offset * elem_size(buffer->type);
-    return nut_alloc(buffer->type, keep, buffer->channels, from);
+nut_buffer *nut_buffer_clip(nut_buffer *source, int first, int count) {
+    assert(source != NULL);
+    const int available = source->length - first;
+    assert(count < 0 || available >= count);
+    const int keep = (count < 0 || count > available) ? available : count;
+    /* the reference advances the data pointer by `first` elements, not frames */
+    const uint8_t *from = (const uint8_t *)payload(source) + (size_t)first * elem_size(source->type);
+    return nut_alloc(source->type, keep, source->channels, from);
 }
 
-void nut_buffer_set_data(nut_buffer *dst, nut_buffer *src) {
-    assert(dst != NULL && src != NULL);
-    assert(dst->type == src->type);
-    assert(dst->size_bytes == src->size_bytes);
-    memcpy(payload(dst), payload(src), (size_t)dst->size_bytes);
+void nut_buffer_set_data(nut_buffer *target, nut_buffer *origin) {
+    assert(target != NULL && origin != NULL);
+    assert(target->type == origin->type && target->size_bytes == origin->size_bytes);
+    memcpy(payload(target), payload(origin), (size_t)target->size_bytes);
 }
 
-void nut_buffer_append(nut_buffer *dst, nut_buffer *src) {
-    assert(dst != NULL && src != NULL);
-    assert(dst->type == src->type);
-    size_t es = elem_size(dst->type);
-    size_t dst_elems = (size_t)dst->length * (size_t)dst->channels;
-    size_t src_elems = (size_t)src->length * (size_t)src->channels;
-    uint8_t *grown = (uint8_t *)calloc(dst_elems + src_elems ? dst_elems + src_elems : 1, es);
+void nut_buffer_append(nut_buffer *target, nut_buffer *origin) {
+    assert(target != NULL && origin != NULL);
+    assert(target->type == origin->type);
+    size_t es = elem_size(target->type);
+    size_t target_elems = (size_t)target->length * (size_t)target->channels;
+    size_t origin_elems = (size_t)origin->length * (size_t)origin->channels;
+    uint8_t *grown = (uint8_t *)calloc(target_elems + origin_elems ? target_elems + origin_elems : 1, es);
     if (grown == NULL) {
         fprintf(stderr, "nut_buffer_append: out of memory\n");
         exit(EXIT_FAILURE);
     }
-    memcpy(grown, payload(dst), (size_t)dst->size_bytes);
-    memcpy(grown + dst_elems * es, payload(src), (size_t)src->size_bytes);
-    free(payload(dst));
-    set_payload(dst, grown);
-    dst->size_bytes = (int)((dst_elems + src_elems) * es);
-    dst->length += src->length;
+    memcpy(grown, payload(target), (size_t)target->size_bytes);
+    memcpy(grown + target_elems * es, payload(origin), (size_t)origin->size_bytes);
+    free(payload(target));
+    set_payload(target, grown);
+    target->size_bytes = (int)((target_elems + origin_elems) * es);
+    target->length += origin->length;
 }
 
-uint8_t nut_buffer_get_u8(nut_buffer *buffer, int offset) {
-    if (buffer->type == NUT_BUFFER_U8) return buffer->data.u8[offset];
-    return (uint8_t)(buffer->data.f64[offset] * 256.0);
+uint8_t nut_buffer_get_u8(nut_buffer *source, int element) {
+    if (source->type == NUT_BUFFER_U8) return source->data.u8[element];
+    return (uint8_t)(source->data.f64[element] * 256.0);
 }
 
-double nut_buffer_get_f64(nut_buffer *buffer, int offset) {
-    if (buffer->type == NUT_BUFFER_F64) return buffer->data.f64[offset];
-    return buffer->data.u8[offset] / 256.0;
+double nut_buffer_get_f64(nut_buffer *source, int element) {
+    if (source->type == NUT_BUFFER_F64) return source->data.f64[element];
+    return source->data.u8[element] / 256.0;
 }
 
-void nut_buffer_set_u8(nut_buffer *buffer, int offset, uint8_t value) {
-    if (buffer->type == NUT_BUFFER_U8) {
-        buffer->data.u8[offset] = value;
+void nut_buffer_set_u8(nut_buffer *target, int element, uint8_t sample) {
+    if (target->type == NUT_BUFFER_U8) {
+        target->data.u8[element] = sample;
     } else {
-        buffer->data.f64[offset] = value / 256.0;
+        target->data.f64[element] = sample / 256.0;
     }
 }
 
-void nut_buffer_set_f64(nut_buffer *buffer, int offset, double value) {
-    if (buffer->type == NUT_BUFFER_F64) {
-        buffer->data.f64[offset] = value;
+void nut_buffer_set_f64(nut_buffer *target, int element, double sample) {
+    if (target->type == NUT_BUFFER_F64) {
+        target->data.f64[element] = sample;
     } else {
-        buffer->data.u8[offset] = (uint8_t)(value * 256.0);
+        target->data.u8[element] = (uint8_t)(sample * 256.0);
     }
 }
 
-nut_buffer *nut_buffer_convert(nut_buffer *buffer, nut_buffer_type new_type) {
-    assert(buffer != NULL);
-    nut_buffer *out = nut_alloc(new_type, buffer->length, buffer->channels, NULL);
-    int count = buffer->length * buffer->channels;
-    for (int i = 0; i < count; i++) {
-        if (new_type == NUT_BUFFER_U8) {
-            out->data.u8[i] = nut_buffer_get_u8(buffer, i);
-        } else {
-            out->data.f64[i] = nut_buffer_get_f64(buffer, i);
-        }
+nut_buffer *nut_buffer_convert(nut_buffer *source, nut_buffer_type wanted) {
+    assert(source != NULL);
+    nut_buffer *converted = nut_alloc(wanted, source->length, source->channels, NULL);
+    const int total = source->length * source->channels;
+    if (wanted == NUT_BUFFER_U8) {
+        for (int i = 0; i < total; i++) converted->data.u8[i] = nut_buffer_get_u8(source, i);
+    } else {
+        for (int i = 0; i < total; i++) converted->data.f64[i] = nut_buffer_get_f64(source, i);
     }
-    return out;
+    return converted;
 }
 
-void nut_buffer_save(nut_buffer *buffer, const char *fname) {
-    assert(buffer != NULL);
-    FILE *fp = fopen(fname, "wb");
-    if (fp == NULL) return;
-    fwrite(payload(buffer), (size_t)buffer->size_bytes, 1, fp);
-    fclose(fp);
-    printf("Written %s.\n", fname);
+void nut_buffer_save(nut_buffer *source, const char *path) {
+    assert(source != NULL);
+    FILE *out = fopen(path, "wb");
+    if (out == NULL) return;
+    fwrite(payload(source), (size_t)source->size_bytes, 1, out);
+    fclose(out);
+    printf("Written %s.\n", path);
 }
 
-void nut_buffer_free(nut_buffer *buffer) {
-    if (buffer == NULL) return;
-    free(payload(buffer));
-    free(buffer);
+void nut_buffer_free(nut_buffer *victim) {
+    if (victim == NULL) return;
+    free(payload(victim));
+    free(victim);
 }
