@@ -163,6 +163,17 @@ def test_repeated_launches_reset_their_ticket_counters():
     plan.close()
 
 
+def test_zero_frames_and_single_frame():
+    plan = fsea.Plan(4096)
+    assert plan.exec_host(np.zeros(0, np.uint8), 0).shape == (0, 4096)
+    d = DeviceBuffer(4096 * 4)
+    plan.exec_device(d.ptr, 0, d.ptr)                    # no launch, no error
+    iq = synth_iq(1, 2 * 4096)
+    parity.check_mode(plan.exec_host(iq, 1), iq, 4096, 1, 4096, True, 0)
+    d.free()
+    plan.close()
+
+
 def test_f64_input_branch():
     n, nf = 1024, 7
     rng = np.random.default_rng(3)
