@@ -196,7 +196,8 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
     # FFT kernel alone on this rank's shard (HIP events on the launch stream)
     kernel_ms = plan.time_device(iq.data_ptr(), (hi - lo) * rows, px.data_ptr(), 10, stream=stream)
     if dist is not None:
-        tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall, kernel_ms], dtype=torch.float64,
+                          device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kernel_ms = float(tt[0]), float(tt[1])
     check = None
@@ -271,12 +272,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local)
+    # one rank per GPU; FSEA_BENCH_BACKEND=gloo lets several ranks share one GPU to exercise the
+    # N>1 control path on a single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("FSEA_BENCH_BACKEND", "nccl")
+    device_index = local % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
     if args.gpus != world:
         if rank == 0:
