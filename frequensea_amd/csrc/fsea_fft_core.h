@@ -611,6 +611,10 @@ struct FftKernel {
     // when stealing at the very end of a launch.  Counter words sit in separate 128-byte
     // lines: ctr[32 q] = tickets drawn from pool q, ctr[32 POOLS] = finished workgroups;
     // the last workgroup to finish zeroes them for the next launch on this slot.
+    // Sizes whose frames live inside one wavefront have no barrier to publish a ticket with and
+    // thousands of independent waves to average over: they keep a static interleave
+    // (unit = blockIdx + k * gridDim); the ticket scheme is for the multi-wave sizes.
+    static constexpr bool DYNAMIC = !ONE_WAVE;
     static constexpr unsigned POOLS = 8;
     static constexpr unsigned NO_UNIT = 0xffffffffu;
 
@@ -659,10 +663,13 @@ struct FftKernel {
         // the latencies overlap: the ticket for the second unit, unit 0's bytes (HBM
         // starts streaming at once), the register-resident last-pass twiddles, then the
         // middle-pass tables for LDS.
-        size_t u = (size_t)pools.start(cur) + b / POOLS;  // static first unit
-        if (u >= pools.start(cur + 1)) u = n_units;        // more workgroups than units in this pool
+        size_t u = b;  // static interleave (single-wave frames)
         unsigned tick_next = 0;
-        if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+        if constexpr (DYNAMIC) {
+            u = (size_t)pools.start(cur) + b / POOLS;         // static first unit
+            if (u >= pools.start(cur + 1)) u = n_units;       // more workgroups than units in this pool
+            if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+        }
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
 
@@ -694,7 +701,7 @@ struct FftKernel {
         // A workgroup whose static unit does not exist still has to look for work (another
         // pool may be long): resolve its first ticket synchronously.
         unsigned par = 0;
-        if (u >= n_units) {
+        if (DYNAMIC && u >= n_units) {
             if (issuer) {
                 unsigned nu = pools.unit(cur, tick_next);
                 for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
@@ -719,7 +726,7 @@ struct FftKernel {
             // pool it came from is exhausted, steal from the others (synchronous; this only
             // happens at the end of a launch).  Published to the workgroup by the first
             // barrier of this iteration.
-            if (issuer) {
+            if (DYNAMIC && issuer) {
                 unsigned nu = pools.unit(cur, tick_next);
                 for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
                     const unsigned q = (cur + k) % POOLS;
@@ -740,12 +747,15 @@ struct FftKernel {
             lds_write<0>(lds, v, t);
             frame_sync();
             if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
-            if constexpr ((ONE_WAVE && Cfg::WG > 64) || (Cfg::ABL & 2)) __syncthreads();  // publish tk
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
-            const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
-            par ^= 1u;
-            const size_t un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+            size_t un = u + gridDim.x;
+            if constexpr (DYNAMIC) {
+                if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
+                const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
+                par ^= 1u;
+                un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+            }
             load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
             middle_pass<1>(lds, lds_all, v, a, t);
 
@@ -778,7 +788,7 @@ struct FftKernel {
 
         // this worker is done: its outstanding ticket request must have landed before it is
         // counted, so that the last worker's reset cannot be overtaken by a late increment
-        if (issuer) {
+        if (DYNAMIC && issuer) {
             __builtin_amdgcn_s_waitcnt(0);
             const unsigned finished = atomicAdd(a.ctr + 32 * POOLS, 1u);
             if (finished == gridDim.x - 1) {
