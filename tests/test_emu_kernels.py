@@ -112,3 +112,22 @@ def test_tuning_variants(n, variant):
     for mode in (0, 1, 3):
         got = emu_rows(iq, n, nf, mode=mode, grid=2, specialised=(mode == 0), variant=variant)
         parity.check_mode(got, iq, n, nf, n, True, mode)
+
+
+def test_random_geometry_sweep():
+    """Seeded random draws of (size, hop, frame count, mode, flip, grid): overlapped, gapped
+    (hop > N) and tiny hops, ragged frame counts, every epilogue."""
+    rng = np.random.default_rng(2026)
+    for _ in range(28):
+        n = int(rng.choice([128, 256, 512, 1024, 2048, 4096, 8192]))
+        hop = int(rng.choice([8, 16, n // 4, n // 2, n, n + 8, 2 * n]))
+        nf = int(rng.integers(1, 40 if n <= 1024 else 7))
+        mode = int(rng.integers(0, 6))
+        flip = bool(rng.integers(0, 2))
+        grid = int(rng.choice([1, 2, 3, 8]))
+        iq = synth_iq(int(rng.integers(1 << 30)), 2 * ((nf - 1) * hop + n))
+        got = emu_rows(iq, n, nf, hop=hop, flip=flip, mode=mode, grid=grid, specialised=bool(rng.integers(0, 2)))
+        try:
+            parity.check_mode(got, iq, n, nf, hop, flip, mode)
+        except AssertionError as e:
+            raise AssertionError("n=%d hop=%d nf=%d mode=%d flip=%s grid=%d: %s" % (n, hop, nf, mode, flip, grid, e))

@@ -81,6 +81,28 @@ def test_overlapped_frames(n, hop):
     plan.close()
 
 
+def test_random_geometry_sweep_on_gpu():
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        n = int(rng.choice(SIZES))
+        hop = int(rng.choice([8, 16, n // 4, n // 2, n, n + 8, 2 * n]))
+        nf = int(rng.integers(1, 3000 if n <= 1024 else 300))
+        mode = int(rng.integers(0, 6))
+        flip = bool(rng.integers(0, 2))
+        iq = synth_iq(int(rng.integers(1 << 30)), 2 * ((nf - 1) * hop + n))
+        plan = fsea.Plan(n, hop=hop, mode=mode)
+        got = plan.exec_host(iq, nf, flip=flip)
+        k = min(nf, 24)                                   # oracle time: first and last rows
+        rows = np.r_[0:k // 2, nf - (k - k // 2):nf]
+        for f in np.unique(rows):
+            sub = iq[2 * f * hop: 2 * (f * hop + n)]
+            try:
+                parity.check_mode(got[f:f + 1], sub, n, 1, n, flip, mode)
+            except AssertionError as e:
+                raise AssertionError("n=%d hop=%d nf=%d mode=%d flip=%s row %d: %s" % (n, hop, nf, mode, flip, f, e))
+        plan.close()
+
+
 def test_flip_is_bit_exact_identity():
     """flip=1 on raw int8 bytes and flip=0 on the same bytes ^ 0x80 must give identical bits."""
     n, nf = 1024, 64
