@@ -254,8 +254,8 @@ def cpu_baseline(n, hop, cores, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="batch8192x4096", choices=sorted(WORKLOADS) + ["broad"])
     ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
