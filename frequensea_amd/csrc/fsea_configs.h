@@ -35,7 +35,3 @@
 #define FSEA_CFG_8192_B_NOFLOP 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4
 #define FSEA_CFG_8192_B_IO 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6
 #define FSEA_CFG_8192_B_VALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 3
-// half-size exchange, three workgroups per CU (FftCfg<..., TWL, TWR, ABL, HX>)
-#define FSEA_CFG_8192_H 8192, 256, 1, 3, 3, 16, 16, 32, 1, true, false, 0, 1
-#define FSEA_CFG_8192_HB 8192, 256, 1, 3, 3, 16, 32, 16, 1, true, false, 0, 1
-#define FSEA_CFG_4096_H 4096, 128, 1, 3, 3, 16, 16, 16, 1, true, false, 0, 1

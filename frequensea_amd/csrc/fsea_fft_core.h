@@ -144,14 +144,8 @@ enum : int { IN_U8 = 0, IN_F32 = 1 };
 // live in LDS (else they are fetched from the global table every frame);
 // TWR: the last pass keeps its twiddles in registers across the frame loop.
 template <int N_, int T_, int FPW_, int WPE_, int NP_, int R0_, int R1_, int R2_ = 1, int R3_ = 1,
-          bool TWL_ = true, bool TWR_ = true, int ABL_ = 0, int HX_ = 0>
+          bool TWL_ = true, bool TWR_ = true, int ABL_ = 0>
 struct FftCfg {
-    // HX = 1: half-size exchange.  The LDS buffer holds N/2 points; every exchange runs in two
-    // rounds (lanes t < T/2 write, everybody reads rows < R/2; lanes t >= T/2 write, everybody
-    // reads rows >= R/2), and the last pass rebuilds its twiddles from the HI/LO factor tables
-    // every frame instead of keeping them in registers.  Twice the barriers, ~8 % more VALU,
-    // but half the LDS and ~60 fewer VGPRs: three workgroups per CU instead of two.
-    static constexpr int HX = HX_;
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
     static constexpr int ABL = ABL_;
@@ -166,7 +160,7 @@ struct FftCfg {
     static constexpr int tw_len(int i) { return i == 0 ? 0 : (R(i) - 1) * Ns(i); }
     // LDS (in complex = 8-byte units): FPW padded frames, then the middle-pass tables.
     static constexpr int pad(int idx) { return lds_pad<N_ / T_>(idx); }
-    static constexpr int LDS_FRAME = HX_ ? (N_ / 2 + T_) : (N_ + 2 * T_);
+    static constexpr int LDS_FRAME = N_ + 2 * T_;
     static constexpr int lds_tw_off(int i) {
         return i <= 1 ? FPW_ * LDS_FRAME : lds_tw_off(i - 1) + tw_len(i - 1);
     }
@@ -174,10 +168,10 @@ struct FftCfg {
     // HI[N/64] = W^{64 h}, LO[64] = W^{l} the last pass's register twiddles are built from
     static constexpr int TAB_MID = lds_tw_off(NP_ - 1) - FPW_ * LDS_FRAME;
     static constexpr int TAB_HI = N_ / 64, TAB_LO = 64;
-    static constexpr int TAB_SMALL = TAB_MID + ((TWR_ || HX_) ? TAB_HI + TAB_LO : 0);
+    static constexpr int TAB_SMALL = TAB_MID + (TWR_ ? TAB_HI + TAB_LO : 0);
     static constexpr int LDS_HI = FPW_ * LDS_FRAME + TAB_MID;
     static constexpr int LDS_LO = LDS_HI + TAB_HI;
-    static constexpr int LDS_TOTAL = FPW_ * LDS_FRAME + ((TWL_ || TWR_ || HX_) ? TAB_SMALL : 0);
+    static constexpr int LDS_TOTAL = FPW_ * LDS_FRAME + ((TWL_ || TWR_) ? TAB_SMALL : 0);
     static constexpr int LDS_ALLOC = LDS_TOTAL + 2;  // + two ticket words (dynamic frame distribution)
     static_assert(R0_ * R1_ * R2_ * R3_ == N_, "radices must multiply to N");
     static_assert(N_ % T_ == 0, "T must divide N");
@@ -362,7 +356,7 @@ struct FftKernel {
     // into the register-resident last-pass twiddles (and one multiply of the
     // untwiddled row), or applied by the epilogue when those are not in registers.
     static constexpr float SC = (IN == IN_U8) ? (1.0f / 256.0f) : 1.0f;
-    static constexpr bool PRESCALED = (Cfg::TWR || Cfg::HX) && (IN == IN_U8);
+    static constexpr bool PRESCALED = Cfg::TWR && (IN == IN_U8);
     using Raw = RawRow<IN, C0>;
 
     // Frames of one workgroup exchange through LDS.  When a frame lives inside
@@ -502,59 +496,6 @@ struct FftKernel {
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) ld_c<C>(lds + Cfg::pad(C * t + r * STRIDE), v + r * C);
-        }
-    }
-
-    // half-size exchange: rows [0, R/2) of pass I's input live at the same addresses in both
-    // rounds (the second round's writers subtracted N/2 from their positions)
-    template <int I>
-    static __device__ __forceinline__ void lds_read_half(const cf *lds, cf *dst, int t) {
-        constexpr int R = Cfg::R(I), C = Cfg::C(I);
-        constexpr int STRIDE = N / R;
-        static_assert(STRIDE % P == 0 && R % 2 == 0, "half exchange needs affine row addressing");
-        const cf *base = lds + Cfg::pad(C * t);
-#pragma unroll
-        for (int r = 0; r < R / 2; ++r) ld_c<C>(base + r * (STRIDE + 2 * (STRIDE / P)), dst + r * C);
-    }
-
-    // One exchange of the half-size scheme: pass I-1's outputs (in v) -> pass I's inputs (in v).
-    // `after_first_barrier` runs once every lane may read what lane 0 published before it.
-    template <int I, class F>
-    static __device__ __forceinline__ void exchange_half(cf *lds, cf *v, int t, F after_first_barrier) {
-        constexpr int HT = T / 2;
-        static_assert(HT % 64 == 0, "each half must be whole wavefronts");
-        const int h = t / HT;        // wave-uniform
-        const int th = t - h * HT;
-        cf d[P];
-        if (h == 0) lds_write<I - 1>(lds, v, th);
-        frame_sync();
-        after_first_barrier();
-        lds_read_half<I>(lds, d, t);
-        frame_sync();
-        if (h == 1) lds_write<I - 1>(lds, v, th);
-        frame_sync();
-        lds_read_half<I>(lds, d + P / 2, t);
-        frame_sync();
-#pragma unroll
-        for (int i = 0; i < P; ++i) v[i] = d[i];
-    }
-
-    // last-pass twiddles rebuilt from the factor tables: W^{r k} = HI[m >> 6] * LO[m & 63], m = r k
-    static __device__ __forceinline__ void apply_last_twiddles_generated(const cf *lds_all, cf *v, int t) {
-        const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
-        if constexpr (PRESCALED) {
-#pragma unroll
-            for (int c = 0; c < CL; ++c) v[c] = v[c] * cf{SC, SC};  // row 0 has no twiddle
-        }
-#pragma unroll
-        for (int r = 1; r < RL; ++r) {
-#pragma unroll
-            for (int c = 0; c < CL; ++c) {
-                const unsigned m = (unsigned)r * (unsigned)(CL * t + c);
-                cf w = pk_cmul(hi[m >> 6], lo[m & 63u]);
-                if constexpr (PRESCALED) w = w * cf{SC, SC};
-                v[r * CL + c] = pk_cmul(v[r * CL + c], w);
-            }
         }
     }
 
@@ -737,7 +678,7 @@ struct FftKernel {
         // two factor tables: W^{m} = HI[m >> 6] * LO[m & 63].  (Loading those (RL-1) CL twiddles
         // per lane from the full table instead cost 32 MB of L2 traffic per launch and a
         // 5.8 us prologue.)  All of it overlaps the latency of unit 0's bytes requested above.
-        constexpr int TAB_COPY = (Cfg::TWL || Cfg::TWR || Cfg::HX) ? Cfg::TAB_SMALL : 0;
+        constexpr int TAB_COPY = (Cfg::TWL || Cfg::TWR) ? Cfg::TAB_SMALL : 0;
         if constexpr (TAB_COPY > 0) {
             for (int e = tid; e < TAB_COPY; e += Cfg::WG) lds_all[FPW * Cfg::LDS_FRAME + e] = a.tw_small[e];
             __syncthreads();
@@ -803,54 +744,39 @@ struct FftKernel {
             for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
+            lds_write<0>(lds, v, t);
+            frame_sync();
+            if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
+            // prefetch: the next unit is known to every lane now; its bytes stay in flight
+            // during the rest of the transform
             size_t un = u + gridDim.x;
-            // what every lane does once the first barrier of the iteration has published tk:
-            // learn the next unit and request its bytes (they stay in flight during the rest
-            // of the transform)
-            auto fetch_next = [&]() {
-                if constexpr (DYNAMIC) {
-                    if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
-                    const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
-                    par ^= 1u;
-                    un = (nu == NO_UNIT) ? n_units : (size_t)nu;
-                }
-                load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff,
-                         raw);
-            };
-            if constexpr (Cfg::HX) {
-                static_assert(NP == 3 && DYNAMIC && FPW == 1, "half exchange: 3 passes, multi-wave frames");
-                exchange_half<1>(lds, v, t, fetch_next);
-                apply_twiddles<1>(v, lds_all + Cfg::lds_tw_off(1), t);
-#pragma unroll
-                for (int c = 0; c < Cfg::C(1); ++c) dft_regs<Cfg::R(1), Cfg::C(1)>(v + c);
-                exchange_half<2>(lds, v, t, [] {});
-                apply_last_twiddles_generated(lds_all, v, t);
-            } else {
-                lds_write<0>(lds, v, t);
-                frame_sync();
-                if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
-                fetch_next();
-                middle_pass<1>(lds, lds_all, v, a, t);
+            if constexpr (DYNAMIC) {
+                if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
+                const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
+                par ^= 1u;
+                un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+            }
+            load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
+            middle_pass<1>(lds, lds_all, v, a, t);
 
-                // last pass
-                lds_read<LAST>(lds, v, t);
-                frame_sync();  // the buffer is free for the next frame's pass 0
-                if constexpr (Cfg::TWR) {
-                    if constexpr (PRESCALED) {
+            // last pass
+            lds_read<LAST>(lds, v, t);
+            frame_sync();  // the buffer is free for the next frame's pass 0
+            if constexpr (Cfg::TWR) {
+                if constexpr (PRESCALED) {
 #pragma unroll
-                        for (int c = 0; c < CL; ++c) v[c] = v[c] * cf{SC, SC};  // row 0 has no twiddle
-                    }
-#pragma unroll
-                    for (int r = 1; r < RL; ++r) {
-#pragma unroll
-                        for (int c = 0; c < CL; ++c) {
-                            if constexpr (Cfg::ABL & 4) v[r * CL + c] += twl[(r - 1) * CL + c];
-                            else v[r * CL + c] = pk_cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
-                        }
-                    }
-                } else {
-                    apply_twiddles<LAST>(v, a.tw[LAST], t);
+                    for (int c = 0; c < CL; ++c) v[c] = v[c] * cf{SC, SC};  // row 0 has no twiddle
                 }
+#pragma unroll
+                for (int r = 1; r < RL; ++r) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) {
+                        if constexpr (Cfg::ABL & 4) v[r * CL + c] += twl[(r - 1) * CL + c];
+                        else v[r * CL + c] = pk_cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
+                    }
+                }
+            } else {
+                apply_twiddles<LAST>(v, a.tw[LAST], t);
             }
 #pragma unroll
             for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);

@@ -14,10 +14,10 @@ from frequensea_amd import fsea  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 VARIANTS = {
-    8192: ["", "A", "B", "D", "H", "HB", "notwl", "notwr",
+    8192: ["", "A", "B", "D", "notwl", "notwr",
            "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu"],
     1024: ["", "B", "C", "D"],
-    4096: ["", "B", "C", "D", "H"],
+    4096: ["", "B", "C", "D"],
     128: [""], 256: [""], 512: [""], 2048: ["", "B", "C"], 16384: ["", "B"],
 }
 TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch

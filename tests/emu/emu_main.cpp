@@ -106,9 +106,6 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
         EMU_VARIANT(8192, "A", FSEA_CFG_8192_A)
         EMU_VARIANT(8192, "B", FSEA_CFG_8192_B)
         EMU_VARIANT(8192, "D", FSEA_CFG_8192_D)
-        EMU_VARIANT(8192, "H", FSEA_CFG_8192_H)
-        EMU_VARIANT(8192, "HB", FSEA_CFG_8192_HB)
-        EMU_VARIANT(4096, "H", FSEA_CFG_4096_H)
         EMU_VARIANT(8192, "notwl", FSEA_CFG_8192_NOTWL)
         EMU_VARIANT(8192, "notwr", FSEA_CFG_8192_NOTWR)
         EMU_VARIANT(1024, "B", FSEA_CFG_1024_B)

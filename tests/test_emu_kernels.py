@@ -102,7 +102,7 @@ def test_edge_inputs():
 
 
 @pytest.mark.parametrize("n,variant", [(8192, "A"), (8192, "B"), (8192, "D"),
-                                       (8192, "notwl"), (8192, "notwr"), (8192, "H"), (8192, "HB"), (4096, "H"), (1024, "B"), (1024, "C"), (1024, "D"),
+                                       (8192, "notwl"), (8192, "notwr"), (1024, "B"), (1024, "C"), (1024, "D"),
                                        (4096, "B"), (4096, "C"), (4096, "D"), (16384, "B"), (2048, "B"),
                                        (2048, "C")])
 def test_tuning_variants(n, variant):
