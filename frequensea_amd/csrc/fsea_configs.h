@@ -9,8 +9,8 @@
 #define FSEA_CFG_512 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true
 #define FSEA_CFG_1024 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true
 #define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true
-// multi-wave frames
-#define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true
+// multi-wave frames (4096: 16 points per lane, four workgroups per CU)
+#define FSEA_CFG_4096 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true
 #define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true
 
@@ -23,7 +23,7 @@
 #define FSEA_CFG_1024_B 1024, 64, 4, 4, 3, 16, 16, 4, 1, true, true
 #define FSEA_CFG_1024_C 1024, 64, 4, 4, 3, 4, 16, 16, 1, true, true
 #define FSEA_CFG_1024_D 1024, 32, 4, 2, 2, 32, 32, 1, 1, true, true
-#define FSEA_CFG_4096_B 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true
+#define FSEA_CFG_4096_B 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true
 #define FSEA_CFG_4096_C 4096, 128, 2, 2, 3, 16, 8, 32, 1, true, true
 #define FSEA_CFG_4096_D 4096, 128, 2, 2, 3, 8, 16, 32, 1, true, true
 #define FSEA_CFG_16384_B 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true

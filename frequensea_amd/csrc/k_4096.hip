@@ -1,4 +1,4 @@
-// N = 4096: two wavefronts per frame, 16 x 16 x 16.
+// N = 4096: 256 lanes x 16 points, 16 x 16 x 16, four workgroups per CU.
 #include "fsea_configs.h"
 #include "fsea_registry.h"
 FSEA_DEFINE_KERNEL(fsea_fft4096, "", FSEA_CFG_4096)
