@@ -196,6 +196,37 @@ def test_zero_frames_and_single_frame():
     plan.close()
 
 
+def test_concurrent_launches_of_one_plan_on_two_streams():
+    """Every launch draws its own ticket-counter slot, so launches of one plan may overlap on
+    different streams.  Two HIP streams, interleaved launches into separate outputs."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    streams = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for st in streams:
+        assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+    n, nf = 8192, 700
+    plan = fsea.Plan(n)
+    iqs = [synth_iq(900 + k, 2 * nf * n) for k in range(2)]
+    d_in = [DeviceBuffer(iq.nbytes).upload(iq) for iq in iqs]
+    d_out = [DeviceBuffer(nf * n * 4) for _ in range(2)]
+    for rep in range(40):
+        for k in range(2):
+            plan.exec_device(d_in[k].ptr, nf, d_out[k].ptr, stream=streams[k].value)
+    for st in streams:
+        assert hip.hipStreamSynchronize(st) == 0
+    for k in range(2):
+        got = d_out[k].download(np.float32, (nf, n))
+        for f in (0, 1, nf // 2, nf - 2, nf - 1):
+            parity.check_float(got[f], O.rows(iqs[k][2 * f * n: 2 * (f + 1) * n], 1, n)[0])
+        d_in[k].free()
+        d_out[k].free()
+    for st in streams:
+        hip.hipStreamDestroy(st)
+    plan.close()
+
+
 def test_f64_input_branch():
     n, nf = 1024, 7
     rng = np.random.default_rng(3)
