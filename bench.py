@@ -68,7 +68,8 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
 
     n, frames, hop = WORKLOADS[workload]
     dev = torch.device("cuda", torch.cuda.current_device())
-    plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_MAG_F32, device=dev.index)
+    plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_MAG_F32, device=dev.index,
+                     variant=os.environ.get("FSEA_BENCH_VARIANT"))  # tuning hook; unset = the default kernel
     in_bytes = plan.in_bytes(frames)
     host = synth_batch(3 + 1000 * rank, in_bytes)
     ins, outs = [], []

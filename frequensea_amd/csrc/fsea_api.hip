@@ -32,6 +32,8 @@ extern "C" int fsea_kernels_var8192b(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_varsmall(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_varmid(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_ablate(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_exp(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_exp2(fsea::KernelEntry *out, int cap);
 
 #define FSEA_CTR_SLOTS 64u
 #define FSEA_CTR_WORDS (9u * 32u)  // 8 ticket pools + the finished-workgroups word, one 128-byte line each
@@ -66,7 +68,7 @@ const std::vector<fsea::KernelEntry> &registry() {
         int (*lists[])(fsea::KernelEntry *, int) = {fsea_kernels_small, fsea_kernels_1024, fsea_kernels_2048,
                                                     fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384,
                                                     fsea_kernels_var8192a, fsea_kernels_var8192b, fsea_kernels_varsmall,
-                                                    fsea_kernels_varmid, fsea_kernels_ablate};
+                                                    fsea_kernels_varmid, fsea_kernels_ablate, fsea_kernels_exp, fsea_kernels_exp2};
         for (auto fn : lists) {
             int n = fn(tmp, 32);
             for (int i = 0; i < n; ++i) v.push_back(tmp[i]);

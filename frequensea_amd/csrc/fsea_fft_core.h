@@ -139,13 +139,24 @@ enum : int {
 };
 enum : int { IN_U8 = 0, IN_F32 = 1 };
 
+#ifndef FSEA_DEFAULT_OPT
+#define FSEA_DEFAULT_OPT 0
+#endif
+
 // N: transform size; T: threads per frame; FPW: frames per workgroup;
 // NP passes of radix R0..R3 (unused = 1).  TWL: middle-pass twiddle tables
 // live in LDS (else they are fetched from the global table every frame);
 // TWR: the last pass keeps its twiddles in registers across the frame loop.
 template <int N_, int T_, int FPW_, int WPE_, int NP_, int R0_, int R1_, int R2_ = 1, int R3_ = 1,
-          bool TWL_ = true, bool TWR_ = true, int ABL_ = 0>
+          bool TWL_ = true, bool TWR_ = true, int ABL_ = 0, int OPT_ = FSEA_DEFAULT_OPT>
 struct FftCfg {
+    // OPT: schedule options (all give identical results):
+    // 1 = the "everyone has read" barrier of an exchange sits right before the next writes into
+    //     the buffer (after the butterflies) instead of right after the reads;
+    // 2 = the reads of an exchange stay one batch (scheduling fence behind them), the waits
+    //     for them become progressive;
+    // 4 = a middle pass fetches all its twiddles from LDS together with the data.
+    static constexpr int OPT = OPT_;
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
     static constexpr int ABL = ABL_;
@@ -358,6 +369,15 @@ struct FftKernel {
     static constexpr float SC = (IN == IN_U8) ? (1.0f / 256.0f) : 1.0f;
     static constexpr bool PRESCALED = Cfg::TWR && (IN == IN_U8);
     using Raw = RawRow<IN, C0>;
+    // The barrier that separates a pass's LDS reads from the next writes into the same buffer
+    // may sit right before those writes (after the butterflies) instead of right after the
+    // reads: the reads' latency overlaps the butterflies and the waves' skew is absorbed by them.
+    static constexpr bool LAZY_SYNC = (Cfg::OPT & 1) != 0;
+    static constexpr bool BATCH_READS = (Cfg::OPT & 2) != 0;
+    static constexpr bool TW_HOIST = (Cfg::OPT & 4) != 0;
+    static __device__ __forceinline__ void after_reads() {
+        if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
+    }
 
     // Frames of one workgroup exchange through LDS.  When a frame lives inside
     // a single wavefront no s_barrier is needed: LDS operations of one wave
@@ -372,6 +392,13 @@ struct FftKernel {
         } else {
             __syncthreads();
         }
+    }
+
+    // the compiler would otherwise hoist the s_barrier above the butterflies (VALU work is not
+    // ordered against it), which is the eager placement again
+    static __device__ __forceinline__ void lazy_sync() {
+        if constexpr (!ONE_WAVE) __builtin_amdgcn_sched_barrier(0);
+        frame_sync();
     }
 
     static constexpr uint32_t IN_BPS = (IN == IN_U8) ? 2 : 8;  // input bytes per complex sample
@@ -504,12 +531,30 @@ struct FftKernel {
     static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t) {
         if constexpr (I < LAST) {
             constexpr int R = Cfg::R(I), C = Cfg::C(I);
-            lds_read<I>(lds, v, t);
-            frame_sync();  // everyone has read before anyone overwrites
             const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
-            apply_twiddles<I>(v, tw, t);
+            if constexpr (TW_HOIST && (Cfg::Ns(I) % C == 0)) {
+                constexpr int Ns = Cfg::Ns(I);
+                cf w[(R - 1) * C];
+                const int k0 = (C * t) % Ns;
+#pragma unroll
+                for (int r = 1; r < R; ++r) ld_c<C>(tw + (r - 1) * Ns + k0, w + (r - 1) * C);
+                lds_read<I>(lds, v, t);
+                after_reads();
+                if constexpr (!LAZY_SYNC) frame_sync();
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v[r * C + c] = pk_cmul(v[r * C + c], w[(r - 1) * C + c]);
+                }
+            } else {
+                lds_read<I>(lds, v, t);
+                after_reads();
+                if constexpr (!LAZY_SYNC) frame_sync();  // everyone has read before anyone overwrites
+                apply_twiddles<I>(v, tw, t);
+            }
 #pragma unroll
             for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0>(v + c);
+            if constexpr (LAZY_SYNC) lazy_sync();  // same barrier, after this wave's butterflies
             lds_write<I>(lds, v, t);
             frame_sync();
             middle_pass<I + 1>(lds, lds_all, v, a, t);
@@ -744,6 +789,7 @@ struct FftKernel {
             for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
+            if constexpr (LAZY_SYNC) lazy_sync();  // the previous frame's last read is complete everywhere
             lds_write<0>(lds, v, t);
             frame_sync();
             if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
@@ -761,7 +807,8 @@ struct FftKernel {
 
             // last pass
             lds_read<LAST>(lds, v, t);
-            frame_sync();  // the buffer is free for the next frame's pass 0
+            after_reads();
+            if constexpr (!LAZY_SYNC) frame_sync();  // the buffer is free for the next frame's pass 0
             if constexpr (Cfg::TWR) {
                 if constexpr (PRESCALED) {
 #pragma unroll

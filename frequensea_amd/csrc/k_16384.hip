@@ -1,4 +1,4 @@
-// N = 16384: 512 lanes x 32 points, 32 x 32 x 16, one workgroup per CU.
+// N = 16384: 512 lanes x 32 points, 16 x 32 x 32, one workgroup per CU.
 #include "fsea_configs.h"
 #include "fsea_registry.h"
 FSEA_DEFINE_KERNEL(fsea_fft16384, "", FSEA_CFG_16384)

@@ -1,4 +1,4 @@
-// Tuning variants of the 2048/4096/16384-point kernels (last pass radix 32).
+// Tuning variants of the 2048/4096/16384-point kernels (other radix orders).
 #include "fsea_configs.h"
 #include "fsea_registry.h"
 FSEA_DEFINE_KERNEL(fsea_fft4096C, "C", FSEA_CFG_4096_C)

@@ -14,11 +14,11 @@ from frequensea_amd import fsea  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 VARIANTS = {
-    8192: ["", "A", "B", "D", "notwl", "notwr",
+    8192: ["", "x0", "x7", "A", "B", "D", "notwl", "notwr",
            "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu"],
-    1024: ["", "B", "C", "D"],
-    4096: ["", "B", "C", "D"],
-    128: [""], 256: [""], 512: [""], 2048: ["", "B", "C"], 16384: ["", "B"],
+    1024: ["", "x0", "B", "C", "D"],
+    4096: ["", "x0", "B", "C", "D"],
+    128: [""], 256: [""], 512: [""], 2048: ["", "x0", "B", "C"], 16384: ["", "B"],
 }
 TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch
 ROUNDS = 7
@@ -42,7 +42,10 @@ def main():
         frames = TOTAL_SAMPLES // n
         want = O.rows(host[: 2 * n * 3], 3, n)
         plans = []
-        for var in VARIANTS.get(n, [""]):
+        names = VARIANTS.get(n, [""])
+        if os.environ.get("TUNE_VARIANTS"):  # e.g. TUNE_VARIANTS=-,x1,x3 ("-" = the default kernel)
+            names = ["" if v == "-" else v for v in os.environ["TUNE_VARIANTS"].split(",")]
+        for var in names:
             try:
                 plans.append((var, fsea.Plan(n, variant=var)))
             except fsea.FseaError as e:

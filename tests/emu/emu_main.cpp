@@ -103,6 +103,11 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     if (!v.empty()) {
 #define EMU_VARIANT(NN, NAME, CFG) \
     if (n == NN && v == NAME) return dispatch<fsea::FftCfg<CFG>>(in_kind, mt, a, grid);
+        EMU_VARIANT(8192, "x0", FSEA_CFG_8192_X0)
+        EMU_VARIANT(8192, "x7", FSEA_CFG_8192_X7)
+        EMU_VARIANT(4096, "x0", FSEA_CFG_4096_X0)
+        EMU_VARIANT(2048, "x0", FSEA_CFG_2048_X0)
+        EMU_VARIANT(1024, "x0", FSEA_CFG_1024_X0)
         EMU_VARIANT(8192, "A", FSEA_CFG_8192_A)
         EMU_VARIANT(8192, "B", FSEA_CFG_8192_B)
         EMU_VARIANT(8192, "D", FSEA_CFG_8192_D)

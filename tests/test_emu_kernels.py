@@ -101,7 +101,7 @@ def test_edge_inputs():
     assert emu_rows(z, n, 0).shape == (0, n)
 
 
-@pytest.mark.parametrize("n,variant", [(8192, "A"), (8192, "B"), (8192, "D"),
+@pytest.mark.parametrize("n,variant", [(8192, "x0"), (8192, "x7"), (4096, "x0"), (2048, "x0"), (1024, "x0"), (8192, "A"), (8192, "B"), (8192, "D"),
                                        (8192, "notwl"), (8192, "notwr"), (1024, "B"), (1024, "C"), (1024, "D"),
                                        (4096, "B"), (4096, "C"), (4096, "D"), (16384, "B"), (2048, "B"),
                                        (2048, "C")])
