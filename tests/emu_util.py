@@ -1,6 +1,7 @@
 """Builds and drives tests/emu/libfsea_emu.so: the real kernel source compiled for the CPU
 (TEST-ONLY; see tests/emu/hip/hip_runtime.h)."""
 import ctypes
+import fcntl
 import os
 import subprocess
 
@@ -21,10 +22,19 @@ def emu_lib():
         deps = [src, os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")] + [
             os.path.join(csrc, f) for f in ("fsea_fft_core.h", "fsea_configs.h", "fsea_tables.h")] + [
             os.path.join(ROOT, "tests", "emu", "fsea_pk_asm.h")]
-        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-            subprocess.check_call(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread",
-                                   "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu"),
-                                   "-I" + csrc, src, "-o", out])
+        def stale():
+            return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+        if stale():
+            # pytest-xdist workers may get here together: one builds, the others wait for the lock
+            with open(out + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if stale():
+                    tmp = "%s.%d.tmp" % (out, os.getpid())
+                    subprocess.check_call(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread",
+                                           "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu"),
+                                           "-I" + csrc, src, "-o", tmp])
+                    os.replace(tmp, out)
         L = ctypes.CDLL(out)
         L.emu_fft.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                               ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
