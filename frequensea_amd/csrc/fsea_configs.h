@@ -7,12 +7,12 @@
 #define FSEA_CFG_128 128, 8, 32, 2, 2, 16, 8, 1, 1, true, true
 #define FSEA_CFG_256 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true
 #define FSEA_CFG_512 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true
-#define FSEA_CFG_1024 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 2
-#define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 6
+#define FSEA_CFG_1024 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 10
+#define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 14
 // multi-wave frames (4096: 16 points per lane, four workgroups per CU)
-#define FSEA_CFG_4096 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 2
-#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 6
-#define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true
+#define FSEA_CFG_4096 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 10
+#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 14
+#define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 8
 
 // ---- tuning variants (selected with fsea_plan_create_variant; not the defaults) ----
 #define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true

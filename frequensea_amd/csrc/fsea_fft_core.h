@@ -126,6 +126,43 @@ __device__ __forceinline__ void dft_regs(cf *x) {
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
 
+// The same DFT with the inter-pass twiddle multiply x[i] *= tw[(i - 1) TS] (i >= 1) fused into
+// the first butterfly level, whose own twiddle is 1: with a = x[i] tw_i and b = x[i + R/2] tw_j,
+//   plus = a + b = pk_cmul_add(x[i + R/2], tw_j, a)   2 pk_fma
+//   minus = 2 a - plus                                  1 pk_fma
+// i.e. 5 packed ops per pair instead of 6 (3 instead of 4 for the untwiddled row 0).
+// SC0: scale applied to row 0 (the other rows carry it in their twiddles), 1 = none.
+template <int R, int S, int TS>
+__device__ __forceinline__ void dft_regs_tw(cf *x, const cf *tw, float sc0) {
+    static_assert(R >= 4 && R <= 64 && (R & (R - 1)) == 0, "radix must be 4..64");
+    constexpr int BITS = ilog2c(R);
+    cf y[R];
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+        cf a = x[i * S];
+        if (i == 0) {
+            if (sc0 != 1.0f) a = a * cf{sc0, sc0};
+        } else {
+            a = pk_cmul(a, tw[(i - 1) * TS]);
+        }
+        const cf plus = pk_cmul_add(x[(i + R / 2) * S], tw[(i + R / 2 - 1) * TS], a);
+        y[bitrev_c(i, BITS)] = plus;
+        y[bitrev_c(i + R / 2, BITS)] = cf_fma(a, cf{2.0f, 2.0f}, -plus);
+    }
+#pragma unroll
+    for (int half = 2; half < R; half <<= 1) {
+#pragma unroll
+        for (int base = 0; base < R; base += 2 * half) {
+#pragma unroll
+            for (int k = 0; k < half; ++k) {
+                bfly_const(2 * half, k, y[base + k], y[base + k + half]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) x[i * S] = y[i];
+}
+
 // ---------------------------------------------------------------------------
 // configuration
 // ---------------------------------------------------------------------------
@@ -155,7 +192,9 @@ struct FftCfg {
     //     the buffer (after the butterflies) instead of right after the reads;
     // 2 = the reads of an exchange stay one batch (scheduling fence behind them), the waits
     //     for them become progressive;
-    // 4 = a middle pass fetches all its twiddles from LDS together with the data.
+    // 4 = a middle pass fetches all its twiddles from LDS together with the data;
+    // 8 = the twiddle multiply is fused into the first butterfly level (dft_regs_tw; one packed
+    //     op less per pair, rounding differs in the last bit).
     static constexpr int OPT = OPT_;
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
@@ -375,6 +414,7 @@ struct FftKernel {
     static constexpr bool LAZY_SYNC = (Cfg::OPT & 1) != 0;
     static constexpr bool BATCH_READS = (Cfg::OPT & 2) != 0;
     static constexpr bool TW_HOIST = (Cfg::OPT & 4) != 0;
+    static constexpr bool TW_FUSE = (Cfg::OPT & 8) != 0 && (Cfg::ABL & 4) == 0;
     static __device__ __forceinline__ void after_reads() {
         if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
     }
@@ -541,10 +581,15 @@ struct FftKernel {
                 lds_read<I>(lds, v, t);
                 after_reads();
                 if constexpr (!LAZY_SYNC) frame_sync();
+                if constexpr (TW_FUSE) {
 #pragma unroll
-                for (int r = 1; r < R; ++r) {
+                    for (int c = 0; c < C; ++c) dft_regs_tw<R, C, C>(v + c, w + c, 1.0f);
+                } else {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) v[r * C + c] = pk_cmul(v[r * C + c], w[(r - 1) * C + c]);
+                    for (int r = 1; r < R; ++r) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) v[r * C + c] = pk_cmul(v[r * C + c], w[(r - 1) * C + c]);
+                    }
                 }
             } else {
                 lds_read<I>(lds, v, t);
@@ -552,8 +597,10 @@ struct FftKernel {
                 if constexpr (!LAZY_SYNC) frame_sync();  // everyone has read before anyone overwrites
                 apply_twiddles<I>(v, tw, t);
             }
+            if constexpr (!(TW_FUSE && TW_HOIST && (Cfg::Ns(I) % C == 0))) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0>(v + c);
+                for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0>(v + c);
+            }
             if constexpr (LAZY_SYNC) lazy_sync();  // same barrier, after this wave's butterflies
             lds_write<I>(lds, v, t);
             frame_sync();
@@ -809,7 +856,10 @@ struct FftKernel {
             lds_read<LAST>(lds, v, t);
             after_reads();
             if constexpr (!LAZY_SYNC) frame_sync();  // the buffer is free for the next frame's pass 0
-            if constexpr (Cfg::TWR) {
+            if constexpr (Cfg::TWR && TW_FUSE) {
+#pragma unroll
+                for (int c = 0; c < CL; ++c) dft_regs_tw<RL, CL, CL>(v + c, twl + c, PRESCALED ? SC : 1.0f);
+            } else if constexpr (Cfg::TWR) {
                 if constexpr (PRESCALED) {
 #pragma unroll
                     for (int c = 0; c < CL; ++c) v[c] = v[c] * cf{SC, SC};  // row 0 has no twiddle
@@ -825,8 +875,10 @@ struct FftKernel {
             } else {
                 apply_twiddles<LAST>(v, a.tw[LAST], t);
             }
+            if constexpr (!(Cfg::TWR && TW_FUSE)) {
 #pragma unroll
-            for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
+                for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
+            }
             epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
             u = un;
             if (a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * b + 8 + iter] = wall_clock64();

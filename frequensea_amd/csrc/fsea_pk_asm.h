@@ -22,6 +22,14 @@ __device__ __forceinline__ cf pk_cmul(cf a, cf w) {
     return t;
 }
 
+// c + a * w with the same two-instruction shape (the product's first half takes c as addend).
+__device__ __forceinline__ cf pk_cmul_add(cf a, cf w, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(w), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(a), "v"(w));
+    return t;
+}
+
 // Diagnostics only (FSEA_TRACE): where a workgroup runs.
 __device__ __forceinline__ unsigned read_hw_id() {
     unsigned v;

@@ -35,6 +35,8 @@ def main():
     L = fsea.hip_lib()
     rng = np.random.default_rng(1)
     host = rng.integers(-70, 70, 2 * TOTAL_SAMPLES, dtype=np.int8).view(np.uint8)
+    if os.environ.get("TUNE_CONST_INPUT"):  # how much of the time is data-dependent (power)?
+        host[:] = 0x80
     d_in = dev_alloc(host.nbytes)
     d_out = dev_alloc(4 * TOTAL_SAMPLES)
     fsea._check(L.fsea_copy_to_device(0, d_in, host.ctypes.data, host.nbytes))
