@@ -5,9 +5,13 @@
  *   tile for frequency f is pasted at x = k * WIDTH_STEP with dst = max(dst, src),
  *   WIDTH_STEP = FFT_SIZE / (SAMPLE_RATE / FREQUENCY_STEP)  (integer division, as the reference),
  *   IMAGE_WIDTH = FFT_SIZE + FREQUENCY_RANGE * WIDTH_STEP.
- * The tick marks and TrueType labels of c/fft-stitch.c:191-217 are not drawn.
+ * With --footer F the image gets F extra rows carrying the frequency ruler of c/fft-stitch.c:191-217
+ * (banner lines, 0.1 MHz and 1 MHz ticks, "%.2f" MHz labels; include/imgaxis.h -- the labels use a
+ * built-in dot-matrix font, not the reference's TrueType face).  The reference's fixed layout is
+ * --rows 11211 --footer 600.
  *
- * usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--dir DIR] [--device D]
+ * usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--footer F] [--dir DIR]
+ *                        [--device D]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +19,7 @@
 
 #include "easypng.h"
 #include "fsea.h"
+#include "imgaxis.h"
 
 static void die(const char *what) {
     fprintf(stderr, "fsea-fft-stitch: %s: %s\n", what, fsea_last_error_string());
@@ -22,7 +27,7 @@ static void die(const char *what) {
 }
 
 int main(int argc, char **argv) {
-    int broad = 0, device = 0, rows = -1;
+    int broad = 0, device = 0, rows = -1, footer = 0;
     double start = -1, end = -1, step = -1;
     const char *dir = ".";
     for (int i = 1; i < argc; i++) {
@@ -31,6 +36,7 @@ int main(int argc, char **argv) {
         else if (strcmp(argv[i], "--end") == 0 && i + 1 < argc) end = atof(argv[++i]);
         else if (strcmp(argv[i], "--step") == 0 && i + 1 < argc) step = atof(argv[++i]);
         else if (strcmp(argv[i], "--rows") == 0 && i + 1 < argc) rows = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--footer") == 0 && i + 1 < argc) footer = atoi(argv[++i]);
         else if (strcmp(argv[i], "--dir") == 0 && i + 1 < argc) dir = argv[++i];
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = atoi(argv[++i]);
     }
@@ -86,13 +92,30 @@ int main(int argc, char **argv) {
         }
         free(tile);
     }
-    uint8_t *image = (uint8_t *)malloc((size_t)image_width * image_height);
+    const uint32_t full_height = image_height + (footer > 0 ? (uint32_t)footer : 0);
+    uint8_t *image = (uint8_t *)calloc((size_t)image_width * full_height, 1);
     if (fsea_copy_to_host(device, image, d_image, (size_t)image_width * image_height) != 0) die("fsea_copy_to_host");
+    if (footer > 0) {
+        printf("Adding markers...\n");
+        img_axis_config axis;
+        memset(&axis, 0, sizeof(axis));
+        axis.fft_size = fft_size;
+        axis.rows = image_height;
+        axis.sample_rate = sample_rate;
+        axis.frequency_step = step_hz;
+        axis.frequency_start = (uint64_t)(start * 1e6 + 0.5);
+        axis.frequency_end = (uint64_t)(end * 1e6 + 0.5);
+        axis.minor_tick_rate = 100000;
+        axis.major_tick_rate = 1000000;
+        axis.font_size_px = 48;
+        axis.line_color = 255;
+        img_draw_frequency_axis(image, image_width, full_height, &axis);
+    }
     char out_name[512];
     if (broad) snprintf(out_name, sizeof(out_name), "%s/broad-stitched-%.0f-%.0f.png", dir, start, end);
     else snprintf(out_name, sizeof(out_name), "%s/fft-stitched-%.4f-%.4f.png", dir, start, end);
     printf("Saving %s...\n", out_name);
-    int rc = write_gray_png(out_name, (int)image_width, (int)image_height, image);
+    int rc = write_gray_png(out_name, (int)image_width, (int)full_height, image);
     free(image);
     fsea_device_free(device, d_tile);
     fsea_device_free(device, d_image);

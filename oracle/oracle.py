@@ -181,3 +181,47 @@ def time_mag_rows(iq, n_frames, n, hop=None, threads=1):
         return lib().orc_time_mag_rows(_u8p(iq), n_frames, n, hop, _f64p(sink))
     chk = ctypes.c_double(0)
     return lib().orc_time_mag_rows_mt(_u8p(iq), n_frames, n, hop, threads, ctypes.byref(chk))
+
+
+def frequency_axis(image_width, image_height, rows_, fft_size, sample_rate, frequency_step, frequency_start,
+                   frequency_end, minor_tick_rate=100000, major_tick_rate=1000000, line_color=255):
+    """Ruler of the stitched image, numpy restatement of /root/reference/c/fft-stitch.c:56-72,191-217
+    without the glyphs: returns (footer image [image_height][image_width] with banner lines and ticks,
+    [(x, "%.2f" label)] for the major ticks that get a label).  Column 0 / row 0 are never written
+    (img_pixel_put's guard); writes past the last row (the reference's first bottom banner line) are
+    dropped."""
+    img = np.zeros((image_height, image_width), np.uint8)
+
+    def hline(y, x1, x2):
+        if 0 < y < image_height:
+            img[y, max(x1, 1):min(x2, image_width)] = line_color
+
+    def vline(x, y1, y2):
+        if 0 < x < image_width:
+            img[max(y1, 1):min(y2, image_height), x] = line_color
+
+    px_per_hz = fft_size / float(frequency_step) / 2
+    minor, major = px_per_hz * minor_tick_rate, px_per_hz * major_tick_rate
+    banner_y, banner_bottom = rows_, image_height
+    for _ in range(10):
+        hline(banner_y, 0, image_width)
+        hline(banner_bottom, 0, image_width)
+        banner_y += 1
+        banner_bottom -= 1
+    banner_bottom += 1
+    x = 0.0
+    while x < image_width:
+        vline(int(x), banner_y, banner_y + 50)
+        vline(int(x), banner_bottom - 50, banner_bottom)
+        x += minor
+    labels = []
+    freq = frequency_start - sample_rate // 2 + major_tick_rate // 2
+    x = fft_size / float(sample_rate) * (major_tick_rate // 2)
+    while x < image_width:
+        vline(int(x), banner_y, banner_y + 100)
+        vline(int(x), banner_bottom - 100, banner_bottom)
+        if 0 <= freq < frequency_end + sample_rate // 2:
+            labels.append((int(x), "%.2f" % (freq / 1e6)))
+        freq += major_tick_rate
+        x += major
+    return img, labels

@@ -83,3 +83,16 @@ def test_narrow_sweep_overlapping_stitch(tmp_path):
     for k, t in enumerate(tiles):
         O.composite_max(want, np.ascontiguousarray(t), k * step)
     assert img.shape == want.shape and np.array_equal(img, want)
+
+    # the same stitch with the reference's 600-row footer: spectrogram rows unchanged, ruler below
+    # (c/fft-stitch.c:191-217); labels are dot-matrix glyphs, everything else equals the restatement
+    subprocess.run([os.path.join(BIN, "fsea-fft-stitch"), "--start", "1802", "--end", "1806", "--footer", "600",
+                    "--dir", str(tmp_path)], capture_output=True, text=True, check=True)
+    img = _png(tmp_path / "fft-stitched-1802.0000-1806.0000.png")
+    assert img.shape == (rows + 600, want.shape[1]) and np.array_equal(img[:rows], want)
+    axis, labels = O.frequency_axis(want.shape[1], rows + 600, rows, 1024, 5000000, 2000000, 1802000000, 1806000000)
+    markers_y = rows + (600 // 2 - 48 // 2)
+    outside = np.ones(img.shape, bool)
+    outside[markers_y:markers_y + 48] = False
+    assert np.array_equal(img[rows:][outside[rows:]], axis[rows:][outside[rows:]])
+    assert labels[0][1] == "1800.00" and img[markers_y:markers_y + 48, labels[0][0]:].any()

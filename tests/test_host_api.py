@@ -11,6 +11,7 @@ import pytest
 
 import frequensea_amd
 from frequensea_amd import fsea, nrf
+from oracle import oracle as O
 from tests.conftest import ROOT, synth_iq
 
 
@@ -205,3 +206,83 @@ def test_png_writer_and_reader_against_pil(tmp_path):
     assert np.array_equal(np.ctypeslib.as_array(p, shape=(8, 8)), want.astype(np.uint8))
     assert not L.read_gray_png(b"/nonexistent.png", ctypes.byref(w), ctypes.byref(h))
     assert L.write_gray_png(b"/nonexistent-dir/x.png", 4, 4, img.ctypes.data) == -1
+
+
+# ---------------------------------------------------------------------------------------------
+# frequency ruler of the stitched image (include/imgaxis.h; c/fft-stitch.c:56-72,191-217)
+# ---------------------------------------------------------------------------------------------
+class _AxisCfg(ctypes.Structure):
+    _fields_ = [("fft_size", ctypes.c_uint32), ("rows", ctypes.c_uint32), ("sample_rate", ctypes.c_uint32),
+                ("frequency_step", ctypes.c_uint32), ("frequency_start", ctypes.c_uint64),
+                ("frequency_end", ctypes.c_uint64), ("minor_tick_rate", ctypes.c_uint32),
+                ("major_tick_rate", ctypes.c_uint32), ("font_size_px", ctypes.c_uint32),
+                ("line_color", ctypes.c_uint8)]
+
+
+def _draw_axis(width, height, rows_, start, end, font_px, fft_size=1024, step=2000000):
+    L = nrf.nrf_lib()
+    L.img_draw_frequency_axis.restype = ctypes.c_int
+    L.img_draw_frequency_axis.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_AxisCfg)]
+    cfg = _AxisCfg(fft_size, rows_, 5000000, step, start, end, 100000, 1000000, font_px, 255)
+    img = np.zeros((height, width), np.uint8)
+    n = L.img_draw_frequency_axis(img.ctypes.data, width, height, ctypes.byref(cfg))
+    return img, n
+
+
+def test_imgaxis_exports():
+    import re
+    text = open(os.path.join(ROOT, "include", "imgaxis.h")).read()
+    names = re.findall(r"^(?:int|void)\s+(\w+)\(", text, flags=re.M)
+    assert sorted(names) == ["img_draw_frequency_axis", "img_draw_text", "img_hline", "img_pixel_put", "img_vline"]
+    for name in names:
+        assert hasattr(nrf.nrf_lib(), name), name
+
+
+@pytest.mark.parametrize("width,height,rows_,start,end", [
+    (1024 + 4 * 512, 700, 100, 1802000000, 1810000000),       # the reference's 600-row footer
+    (1024 + 299 * 512, 640, 40, 1802000000, 2400000000),      # the reference's full 154112-px sweep width
+    (1024, 300, 64, 100000000, 100000000),
+])
+def test_axis_lines_and_ticks_match_the_restatement(width, height, rows_, start, end):
+    got, n = _draw_axis(width, height, rows_, start, end, 0)
+    want, labels = O.frequency_axis(width, height, rows_, 1024, 5000000, 2000000, start, end)
+    assert np.array_equal(got, want)
+    assert n == len(labels) and n > 0
+    assert not got[:rows_].any()                       # the spectrogram rows are untouched
+    assert not got[:, 0].any()                         # column 0 is never written (reference guard)
+    # minor ticks every 25.6 px (truncated), 50 px long from the inner edge of both banners
+    assert got[rows_ + 10, 25] == 255 and got[rows_ + 10, 51] == 255 and got[rows_ + 10, 26] == 0
+    assert got[rows_ + 59, 51] == 255 and got[rows_ + 60, 51] == 0
+    # first major tick at 1024 / 5e6 * 0.5e6 = 102.4 -> column 102, 100 px long
+    assert got[rows_ + 109, 102] == 255 and got[rows_ + 110, 102] == 0
+
+
+def test_axis_labels_sit_at_the_major_ticks():
+    width, height, rows_ = 1024 + 4 * 512, 700, 100
+    plain, _ = _draw_axis(width, height, rows_, 1802000000, 1810000000, 0)
+    text, n = _draw_axis(width, height, rows_, 1802000000, 1810000000, 48)
+    _, labels = O.frequency_axis(width, height, rows_, 1024, 5000000, 2000000, 1802000000, 1810000000)
+    assert n == len(labels) and labels[0] == (102, "1800.00")
+    extra = (text != plain)
+    assert extra.any() and np.all(text[extra] == 255)
+    ys, xs = np.nonzero(extra)
+    markers_y = rows_ + (600 // 2 - 48 // 2)           # c/fft-stitch.c:36
+    assert ys.min() >= markers_y and ys.max() < markers_y + 7 * (48 // 7)
+    assert xs.min() >= labels[0][0]
+    # "1800.00" starts with the glyph of '1': its 5x7 cell (scaled by 6) has the stem in column 2
+    cell = 48 // 7
+    assert extra[markers_y + 3 * cell, 102 + 2 * cell]
+
+
+def test_dot_matrix_text_advance_and_clipping():
+    L = nrf.nrf_lib()
+    L.img_draw_text.restype = ctypes.c_int
+    L.img_draw_text.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_int, ctypes.c_uint8]
+    img = np.zeros((20, 40), np.uint8)
+    assert L.img_draw_text(img.ctypes.data, 40, 20, b"10.5", 2, 3, 7, 200) == 4 * 6
+    assert img.max() == 200 and img[3:10, 2:7].any() and not img[:3].any()
+    img2 = np.zeros((20, 40), np.uint8)
+    assert L.img_draw_text(img2.ctypes.data, 40, 20, b"888888888", 30, 15, 14, 9) == 9 * 12   # runs off both edges
+    assert img2[15:, 30:].any()
+    assert L.img_draw_text(img2.ctypes.data, 40, 20, b"1", -1, 0, 7, 9) == 0                 # c/fft-stitch.c:130
