@@ -23,6 +23,8 @@ NRF_EXPORTS = [
     "nrf_device_new_with_config", "nrf_device_set_frequency", "nrf_device_set_decode_handler",
     "nrf_device_set_paused", "nrf_device_step", "nrf_device_get_samples_buffer", "nrf_device_free",
     "nrf_fft_new", "nrf_fft_shift", "nrf_fft_process", "nrf_fft_get_buffer", "nrf_fft_free",
+    "nrf_freq_shifter_new", "nrf_freq_shifter_process_samples", "nrf_freq_shifter_process",
+    "nrf_freq_shifter_get_buffer", "nrf_freq_shifter_free",
 ]
 
 
@@ -112,6 +114,16 @@ def nrf_lib():
         L.nrf_fft_get_buffer.argtypes = [vp]
         L.nrf_fft_free.restype = None
         L.nrf_fft_free.argtypes = [vp]
+        L.nrf_freq_shifter_new.restype = vp
+        L.nrf_freq_shifter_new.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.nrf_freq_shifter_process_samples.restype = None
+        L.nrf_freq_shifter_process_samples.argtypes = [vp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.nrf_freq_shifter_process.restype = None
+        L.nrf_freq_shifter_process.argtypes = [vp, NutBufferP]
+        L.nrf_freq_shifter_get_buffer.restype = NutBufferP
+        L.nrf_freq_shifter_get_buffer.argtypes = [vp]
+        L.nrf_freq_shifter_free.restype = None
+        L.nrf_freq_shifter_free.argtypes = [vp]
         _LIB = L
     return _LIB
 

@@ -11,6 +11,8 @@
  *                      HackRF / RTL-SDR drivers are out of scope)
  *   src/nrf.h:128-142  nrf_fft: nrf_fft_new / _shift / _process /
  *                      _get_buffer / _free -- identical signatures
+ *   src/nrf.h:192-207  nrf_freq_shifter, the block lua/fft-shifted.lua puts in
+ *                      front of nrf_fft (host arithmetic, as in the reference)
  * Differences, all invisible to callers: <fftw3.h> is gone, the FFTW-typed
  * members of nrf_fft (touched by nobody outside src/nrf.c) became an opaque
  * backend handle, the history is a ring instead of an 8 MiB memmove per row,
@@ -143,5 +145,29 @@ void nrf_fft_process(nrf_fft *fft, nut_buffer *buffer);
  * nut_buffer_free (src/nrf.c:633-635). */
 nut_buffer *nrf_fft_get_buffer(nrf_fft *fft);
 void nrf_fft_free(nrf_fft *fft);
+
+/* ---- frequency shifter (src/nrf.h:192-207, src/nrf.c:817-870) ------------ */
+
+typedef struct {
+    NRF_BLOCK;
+    int freq_offset; /* Hz */
+    int sample_rate; /* Hz */
+    double cosine;   /* phase carried from block to block, starts at (1, 0) */
+    double sine;
+    nut_buffer *buffer; /* last output, F64 */
+} nrf_freq_shifter;
+
+nrf_freq_shifter *nrf_freq_shifter_new(int freq_offset, int sample_rate);
+/* In place on separate I and Q arrays: (i, q) <- (i, q) rotated by the running phase, which
+ * advances by 2 pi freq_offset / sample_rate per sample.  No offset is added. */
+void nrf_freq_shifter_process_samples(nrf_freq_shifter *shifter, double *samples_i, double *samples_q, int length);
+/* Interleaved 2-channel buffer (u8 values count as u8 / 256.0): rotated samples + 0.5 on both
+ * components go to the shifter's own F64 buffer.  As in the reference that buffer is created with
+ * length = buffer->length * 2 and 2 channels, i.e. twice the room it needs; only the first half is
+ * written (src/nrf.c:851).  nrf_fft_process reads just the first fft_size samples of it. */
+void nrf_freq_shifter_process(nrf_freq_shifter *shifter, nut_buffer *buffer);
+/* Copy of the last output (NULL before the first process call). */
+nut_buffer *nrf_freq_shifter_get_buffer(nrf_freq_shifter *shifter);
+void nrf_freq_shifter_free(nrf_freq_shifter *shifter);
 
 #endif /* NRF_H */

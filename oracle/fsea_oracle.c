@@ -246,6 +246,8 @@ void orc_composite_max(uint8_t *dst, const uint8_t *src, uint32_t dst_x,
 
 /* ---- whole rows --------------------------------------------------------- */
 
+static void orc_epilogue(int n, int mode, const double *tmp_out, void *out_row);
+
 static void orc_one_row(const orc_plan *p, const uint8_t *iq, int flip, int mode,
                         uint8_t *tmp_u8, double *tmp_in, double *tmp_out,
                         void *out_row) {
@@ -257,6 +259,10 @@ static void orc_one_row(const orc_plan *p, const uint8_t *iq, int flip, int mode
     }
     orc_unpack_center_u8(src, (size_t)n, tmp_in);
     orc_plan_exec(p, tmp_in, tmp_out);
+    orc_epilogue(n, mode, tmp_out, out_row);
+}
+
+static void orc_epilogue(int n, int mode, const double *tmp_out, void *out_row) {
     switch (mode) {
     case 0:
         orc_mag_row(tmp_out, n, (double *)out_row);
@@ -306,6 +312,63 @@ int orc_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip,
                     (uint8_t *)out + f * row_bytes);
     }
     free(tmp_u8);
+    free(tmp_in);
+    free(tmp_out);
+    orc_plan_free(&p);
+    return 0;
+}
+
+/* ---- frequency shifter (src/nrf.c:843-866) ------------------------------- */
+
+void orc_freq_shift(const uint8_t *iq_u8, const double *iq_f64, size_t n_samples, int freq_offset,
+                    int sample_rate, double *cosine, double *sine, double *out) {
+    const double tau = 6.283185307179586476925286766559;
+    const double dcos = cos(tau * freq_offset / (double)sample_rate);
+    const double dsin = sin(tau * freq_offset / (double)sample_rate);
+    double c = *cosine, s = *sine;
+    for (size_t k = 0; k < n_samples; k++) {
+        const double vi = iq_u8 ? iq_u8[2 * k] / 256.0 : iq_f64[2 * k];
+        const double vq = iq_u8 ? iq_u8[2 * k + 1] / 256.0 : iq_f64[2 * k + 1];
+        out[2 * k] = vi * c - vq * s + 0.5;
+        out[2 * k + 1] = vi * s + vq * c + 0.5;
+        const double ns = c * dsin + s * dcos;
+        const double nc = c * dcos - s * dsin;
+        s = ns;
+        c = nc;
+    }
+    *cosine = c;
+    *sine = s;
+}
+
+int orc_rows_shifted(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                     double cycles_per_sample, double phase0_cycles, void *out) {
+    orc_plan p;
+    if (mode < 0 || mode > 5) return -2;
+    if (orc_plan_init(&p, n) != 0) return -1;
+    const long double tau = 6.283185307179586476925286766559L;
+    double *shifted = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tmp_in = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tmp_out = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    size_t row_bytes = (mode == 1 || mode == 2) ? (size_t)n
+                       : (mode == 3)            ? sizeof(double) * 2 * (size_t)n
+                                                : sizeof(double) * (size_t)n;
+    for (size_t f = 0; f < n_frames; f++) {
+        for (int k = 0; k < n; k++) {
+            const size_t m = f * hop + (size_t)k;
+            const uint8_t bi = iq[2 * m], bq = iq[2 * m + 1];
+            const double vi = (flip ? (uint8_t)(bi ^ 0x80) : bi) / 256.0;
+            const double vq = (flip ? (uint8_t)(bq ^ 0x80) : bq) / 256.0;
+            long double turns = (long double)phase0_cycles + (long double)cycles_per_sample * (long double)m;
+            turns -= floorl(turns);
+            const double c = (double)cosl(tau * turns), s = (double)sinl(tau * turns);
+            shifted[2 * k] = vi * c - vq * s + 0.5;
+            shifted[2 * k + 1] = vi * s + vq * c + 0.5;
+        }
+        orc_unpack_center_f64(shifted, (size_t)n, tmp_in);
+        orc_plan_exec(&p, tmp_in, tmp_out);
+        orc_epilogue(n, mode, tmp_out, (uint8_t *)out + f * row_bytes);
+    }
+    free(shifted);
     free(tmp_in);
     free(tmp_out);
     orc_plan_free(&p);

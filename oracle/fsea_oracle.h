@@ -90,6 +90,24 @@ void orc_composite_max(uint8_t *dst, const uint8_t *src, uint32_t dst_x,
 int orc_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip,
              int mode, void *out);
 
+/* nrf_freq_shifter_process on interleaved IQ (src/nrf.c:843-866): for every sample,
+ *   out_i = vi*cos - vq*sin + 0.5,  out_q = vi*sin + vq*cos + 0.5,
+ * then (cos, sin) advance by the angle 2*pi*freq_offset/sample_rate through the reference's own
+ * recurrence (new_sin = cos*dsin + sin*dcos; new_cos = cos*dcos - sin*dsin, in double).
+ * vi/vq are nut_buffer_get_f64 values: u8/256.0 for `iq_u8`, or taken from `iq_f64` when
+ * iq_u8 is NULL.  *cosine / *sine carry the state across calls (1, 0 initially). */
+void orc_freq_shift(const uint8_t *iq_u8, const double *iq_f64, size_t n_samples, int freq_offset,
+                    int sample_rate, double *cosine, double *sine, double *out);
+
+/* orc_rows for a frequency-shifted stream: frame f transforms
+ *   x[n] = (-1)^n * ( (u8[m]/256) * e^{+2 pi i (phase0 + m*cycles_per_sample)} + 0.5 (1+i) ),
+ *   m = f*hop + n,
+ * which is nrf_freq_shifter_process followed by nrf_fft_process' F64 branch (src/nrf.c:843-866,
+ * 607-612) with the phase in closed form instead of the recurrence (they agree to ~1e-12 over
+ * 2^17 samples; tests/test_oracle.py checks it).  Modes and `out` as orc_rows. */
+int orc_rows_shifted(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                     double cycles_per_sample, double phase0_cycles, void *out);
+
 /* The reference-shaped per-frame loop used as bench.py's cpu_baseline
  * ("port"): a1 flip -> a4 unpack (n samples) -> a5 FFT -> a7 magnitude, on
  * one core, with a pre-planned twiddle table.  Returns seconds elapsed for

@@ -60,6 +60,11 @@ def lib():
         L.orc_rows.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t,
                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.orc_rows.restype = ctypes.c_int
+        L.orc_freq_shift.argtypes = [c_u8p, c_f64p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, c_f64p, c_f64p, c_f64p]
+        L.orc_freq_shift.restype = None
+        L.orc_rows_shifted.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        L.orc_rows_shifted.restype = ctypes.c_int
         L.orc_time_mag_rows.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, c_f64p]
         L.orc_time_mag_rows.restype = ctypes.c_double
         L.orc_time_mag_rows_mt.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t,
@@ -169,6 +174,42 @@ def rows(iq, n_frames, n, hop=None, flip=True, mode=MODE_MAG):
                         out.ctypes.data_as(ctypes.c_void_p))
     if rc != 0:
         raise ValueError("orc_rows failed: %d" % rc)
+    return out
+
+
+def freq_shift(iq, freq_offset, sample_rate, state=(1.0, 0.0)):
+    """nrf_freq_shifter_process on interleaved IQ (u8 -> u8/256.0, or f64): returns (interleaved f64
+    output, new (cosine, sine) state)."""
+    iq = np.ascontiguousarray(iq).ravel()
+    c, s = ctypes.c_double(state[0]), ctypes.c_double(state[1])
+    out = np.empty(iq.size, np.float64)
+    if iq.dtype == np.uint8:
+        lib().orc_freq_shift(_u8p(iq), None, iq.size // 2, freq_offset, sample_rate, ctypes.byref(c),
+                             ctypes.byref(s), _f64p(out))
+    else:
+        iq = iq.astype(np.float64)
+        lib().orc_freq_shift(None, _f64p(iq), iq.size // 2, freq_offset, sample_rate, ctypes.byref(c),
+                             ctypes.byref(s), _f64p(out))
+    return out, (c.value, s.value)
+
+
+def rows_shifted(iq, n_frames, n, cycles_per_sample, phase0_cycles=0.0, hop=None, flip=True, mode=MODE_MAG):
+    """rows() of the frequency-shifted stream (nrf_freq_shifter -> nrf_fft F64 branch)."""
+    hop = n if hop is None else hop
+    iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
+    need = 2 * ((n_frames - 1) * hop + n) if n_frames else 0
+    if iq.size < need:
+        raise ValueError("iq too short: %d < %d" % (iq.size, need))
+    if mode in (MODE_DB10_U8, MODE_DB5_U8_DCFIX):
+        out = np.empty((n_frames, n), dtype=np.uint8)
+    elif mode == MODE_COMPLEX:
+        out = np.empty((n_frames, n), dtype=np.complex128)
+    else:
+        out = np.empty((n_frames, n), dtype=np.float64)
+    rc = lib().orc_rows_shifted(_u8p(iq), n_frames, n, hop, int(bool(flip)), mode, cycles_per_sample,
+                                phase0_cycles, out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise ValueError("orc_rows_shifted failed: %d" % rc)
     return out
 
 

@@ -286,3 +286,55 @@ def test_dot_matrix_text_advance_and_clipping():
     assert L.img_draw_text(img2.ctypes.data, 40, 20, b"888888888", 30, 15, 14, 9) == 9 * 12   # runs off both edges
     assert img2[15:, 30:].any()
     assert L.img_draw_text(img2.ctypes.data, 40, 20, b"1", -1, 0, 7, 9) == 0                 # c/fft-stitch.c:130
+
+
+# ---------------------------------------------------------------------------------------------
+# nrf_freq_shifter (src/nrf.c:817-870), the block in front of nrf_fft in lua/fft-shifted.lua
+# ---------------------------------------------------------------------------------------------
+def test_freq_shifter_block_matches_the_restatement():
+    L = nrf.nrf_lib()
+    iq = synth_iq(31, 2 * 4096) ^ np.uint8(0x80)
+    sh = L.nrf_freq_shifter_new(150000, 5000000)
+    try:
+        assert not L.nrf_freq_shifter_get_buffer(sh)              # nothing processed yet
+        state = (1.0, 0.0)
+        for block in range(3):                                     # the phase carries over blocks
+            buf = L.nut_buffer_new_u8(4096, 2, iq.ctypes.data)
+            L.nrf_freq_shifter_process(sh, buf)
+            L.nut_buffer_free(buf)
+            out = L.nrf_freq_shifter_get_buffer(sh)
+            c = out.contents
+            # the reference sizes its output by values, not samples (src/nrf.c:851): twice the room
+            assert (c.type, c.length, c.channels, c.size_bytes) == (2, 8192, 2, 8192 * 2 * 8)
+            got = nrf.buffer_to_numpy(L, out)
+            L.nut_buffer_free(out)
+            want, state = O.freq_shift(iq, 150000, 5000000, state)
+            assert np.array_equal(got[:8192], want)                 # same recurrence, same doubles
+            assert not got[8192:].any()
+        # F64 input: values are used as they are
+        f = (iq[:512].astype(np.float64) / 256.0)
+        buf = L.nut_buffer_new_f64(256, 2, f.ctypes.data)
+        L.nrf_freq_shifter_process(sh, buf)
+        L.nut_buffer_free(buf)
+        out = L.nrf_freq_shifter_get_buffer(sh)
+        got = nrf.buffer_to_numpy(L, out)[:512]
+        L.nut_buffer_free(out)
+        want, state = O.freq_shift(f, 150000, 5000000, state)
+        assert np.array_equal(got, want)
+    finally:
+        L.nrf_freq_shifter_free(sh)
+
+
+def test_freq_shifter_process_samples_rotates_in_place():
+    L = nrf.nrf_lib()
+    sh = L.nrf_freq_shifter_new(-250000, 2000000)
+    try:
+        rng = np.random.default_rng(5)
+        i, q = rng.normal(size=1000), rng.normal(size=1000)
+        i0, q0 = i.copy(), q.copy()
+        L.nrf_freq_shifter_process_samples(sh, i.ctypes.data, q.ctypes.data, 600)
+        L.nrf_freq_shifter_process_samples(sh, i[600:].ctypes.data, q[600:].ctypes.data, 400)
+        want = (i0 + 1j * q0) * np.exp(2j * np.pi * (-250000 / 2000000) * np.arange(1000))
+        assert np.abs(i + 1j * q - want).max() < 1e-12           # no 0.5 offset on this entry point
+    finally:
+        L.nrf_freq_shifter_free(sh)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, ROOT
+from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, ROOT, synth_iq
 
 
 def test_flip_identity_all_bytes():
@@ -175,3 +175,56 @@ def test_reference_nut_conventions():
     for k in (0, 1, 128, 255):
         assert L.nut_buffer_get_f64(buf, k) == k / 256.0
     L.nut_buffer_free(buf)
+
+
+# ---------------------------------------------------------------------------------------------
+# frequency shifter in front of the FFT (src/nrf.c:843-866; lua/fft-shifted.lua:52-55)
+# ---------------------------------------------------------------------------------------------
+def test_freq_shift_recurrence_against_closed_form():
+    iq = synth_iq(71, 2 * 131072) ^ 0x80
+    out, state = O.freq_shift(iq, 150000, 5000000)
+    m = np.arange(131072)
+    rot = np.exp(2j * np.pi * (150000 / 5000000) * m)
+    v = (iq[0::2] / 256.0 + 1j * (iq[1::2] / 256.0)) * rot + (0.5 + 0.5j)
+    assert np.abs(out[0::2] + 1j * out[1::2] - v).max() < 1e-10
+    # the state carries the phase across blocks: two half blocks == one block
+    a, st = O.freq_shift(iq[:131072], 150000, 5000000)
+    b, st = O.freq_shift(iq[131072:], 150000, 5000000, st)
+    assert np.abs(np.concatenate([a, b]) - out).max() < 1e-12
+    assert abs(st[0] - state[0]) < 1e-12 and abs(st[1] - state[1]) < 1e-12
+    # f64 input branch (nut_buffer_get_f64 of an F64 buffer is the value itself)
+    c, _ = O.freq_shift(iq[:4096].astype(np.float64) / 256.0, 150000, 5000000)
+    assert np.abs(c - out[:4096]).max() < 1e-15
+
+
+@pytest.mark.parametrize("n", [256, 1024, 8192])
+def test_rows_shifted_is_shifter_then_fft(n):
+    nf, hop = 3, n
+    raw = synth_iq(72 + n, 2 * nf * n)
+    delta = 150000 / 5000000
+    got = O.rows_shifted(raw, nf, n, delta, mode=O.MODE_COMPLEX)
+    shifted, _ = O.freq_shift(O.flip_u8(raw), 150000, 5000000)       # the reference's own chain
+    for f in range(nf):
+        x = O.unpack_center_f64(shifted[2 * f * hop: 2 * (f * hop + n)])
+        assert np.abs(O.fft_forward(x) - got[f]).max() < 1e-9 * n
+    mag = O.rows_shifted(raw, nf, n, delta, mode=O.MODE_MAG)
+    want = np.abs(got)
+    want[:, n // 2] = want[:, n // 2 - 1]
+    assert np.allclose(mag, want, rtol=0, atol=1e-12 * n)
+
+
+def test_rows_shifted_by_whole_bins_rotates_the_spectrum():
+    n, nf, k = 1024, 2, 37
+    raw = synth_iq(73, 2 * nf * n)
+    plain = O.rows(raw, nf, n, mode=O.MODE_COMPLEX)
+    dc = np.zeros(n, complex)
+    dc[n // 2] = 0.5 * n * (1 + 1j)
+    # the unshifted stream already carries 0.5 (1+i) of offset-binary DC in bin n/2; the shifter moves
+    # that with everything else and then adds a new 0.5 (1+i)
+    got = O.rows_shifted(raw, nf, n, k / n, mode=O.MODE_COMPLEX)
+    assert np.abs(got - (np.roll(plain, k, axis=1) + dc)).max() < 1e-8
+    zero = O.rows_shifted(raw, nf, n, 0.0, mode=O.MODE_COMPLEX)
+    assert np.abs(zero - (plain + dc)).max() < 1e-9
+    # a constant phase only rotates the shifted part
+    ph = O.rows_shifted(raw, nf, n, 0.0, 0.25, mode=O.MODE_COMPLEX)
+    assert np.abs(ph - (1j * plain + dc)).max() < 1e-9
