@@ -193,7 +193,7 @@ struct fsea_plan {
     unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x FSEA_CTR_WORDS ticket counters
     std::atomic<unsigned> launch_seq{0};
     unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics
-    int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0;
+    int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0, occ_u8_rot = 0;
     // staging for the host-buffer entry points
     std::mutex mu;
     void *d_in = nullptr;
@@ -232,9 +232,16 @@ unsigned grid_for(const fsea_plan *p, int occ, size_t n_frames) {
 }
 
 int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
-           hipStream_t s) {
+           hipStream_t s, double rot_delta = 0.0, double rot_phase0 = 0.0) {
     if (n_frames == 0) return FSEA_OK;
     fsea::FftArgs a;
+    a.rot_delta = rot_delta;
+    a.rot_phase0 = rot_phase0;
+    if (in_kind == fsea::IN_U8_ROT) {
+        fsea::TwPair rows[32];
+        fsea::build_rotation_rows(p->n, p->entry->radix[0], rot_delta, rows);
+        for (int r = 0; r < 32; ++r) a.rot_row[r] = fsea::cf{rows[r].re, rows[r].im};
+    }
     a.in = d_in;
     a.out = d_out;
     a.n_frames = n_frames;
@@ -247,7 +254,10 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.trace = p->d_trace;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     a.tw_small = p->d_tw;
-    const int occ = (in_kind == fsea::IN_F32) ? p->occ_f32 : (mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8);
+    const int occ = (in_kind == fsea::IN_F32)      ? p->occ_f32
+                    : (in_kind == fsea::IN_U8_ROT) ? p->occ_u8_rot
+                    : (mode == FSEA_MODE_MAG_F32)  ? p->occ_u8_mag
+                                                   : p->occ_u8;
     p->entry->launch(in_kind, a, grid_for(p, occ, n_frames), s);
     FSEA_HIP(hipGetLastError());
     return FSEA_OK;
@@ -325,6 +335,7 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8_mag, e->fn_u8_mag, e->wg, 0);
     if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8, e->fn_u8, e->wg, 0);
     if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_f32, e->fn_f32, e->wg, 0);
+    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8_rot, e->fn_u8_rot, e->wg, 0);
     if (he != hipSuccess) {
         int rc = fail(FSEA_EHIP, "plan setup failed: %s", hipGetErrorString(he));
         fsea_plan_destroy(p);
@@ -398,6 +409,43 @@ int fsea_exec_u8_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip
     if (rc) return rc;
     FSEA_HIP(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
     rc = launch(p, fsea::IN_U8, p->d_in, n_frames, flip, p->mode, p->d_out, p->stream);
+    if (rc) return rc;
+    FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
+    FSEA_HIP(hipStreamSynchronize(p->stream));
+    return FSEA_OK;
+}
+
+int fsea_exec_u8_shifted_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, double cycles_per_sample,
+                                double phase0_cycles, void *d_out, void *stream) {
+    int rc = check_exec_args(p, d_iq, d_out, 16);
+    if (rc) return rc;
+    if (!std::isfinite(cycles_per_sample) || !std::isfinite(phase0_cycles)) {
+        return fail(FSEA_EINVAL, "frequency shift must be finite");
+    }
+    FSEA_HIP(hipSetDevice(p->device));
+    return launch(p, fsea::IN_U8_ROT, d_iq, n_frames, flip, p->mode, d_out, static_cast<hipStream_t>(stream),
+                  cycles_per_sample, phase0_cycles);
+}
+
+int fsea_exec_u8_shifted_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip, double cycles_per_sample,
+                              double phase0_cycles, void *out) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    if (n_frames == 0) return FSEA_OK;
+    if (!iq || !out) return fail(FSEA_EINVAL, "NULL buffer");
+    if (!std::isfinite(cycles_per_sample) || !std::isfinite(phase0_cycles)) {
+        return fail(FSEA_EINVAL, "frequency shift must be finite");
+    }
+    std::lock_guard<std::mutex> lock(p->mu);
+    FSEA_HIP(hipSetDevice(p->device));
+    const size_t in_bytes = 2 * ((n_frames - 1) * (size_t)p->hop + (size_t)p->n);
+    const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
+    int rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes);
+    if (rc) return rc;
+    rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
+    if (rc) return rc;
+    FSEA_HIP(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
+    rc = launch(p, fsea::IN_U8_ROT, p->d_in, n_frames, flip, p->mode, p->d_out, p->stream, cycles_per_sample,
+                phase0_cycles);
     if (rc) return rc;
     FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
     FSEA_HIP(hipStreamSynchronize(p->stream));

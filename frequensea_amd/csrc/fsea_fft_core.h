@@ -174,7 +174,7 @@ enum : int {
     MODE_MAG_NODC = 4,
     MODE_DB_F32 = 5
 };
-enum : int { IN_U8 = 0, IN_F32 = 1 };
+enum : int { IN_U8 = 0, IN_F32 = 1, IN_U8_ROT = 2 };  // IN_U8_ROT: launch selector only (kernel IN = IN_U8, ROT)
 
 #ifndef FSEA_DEFAULT_OPT
 #define FSEA_DEFAULT_OPT 0
@@ -239,6 +239,11 @@ struct FftArgs {
     unsigned long long *trace;  // diagnostics: [grid][32] = wall start/end, shader-clock start/end, HW_ID, XCC_ID, -, -, end of iteration 0..23; or null
     const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
     const cf *tw_small;   // [middle-pass tables | HI | LO], the block copied to LDS (fsea_tables.h)
+    // frequency-shifted input (ROT kernels only; fsea_exec_u8_shifted_*): stream sample m is
+    // multiplied by e^{2 pi i (rot_phase0 + m rot_delta)}, both in turns.  rot_row[r] =
+    // e^{2 pi i rot_delta r N / R0}, the factor between the pass-0 rows of one lane.
+    double rot_delta, rot_phase0;
+    cf rot_row[32];
 };
 
 // ---------------------------------------------------------------------------
@@ -359,15 +364,16 @@ __device__ __forceinline__ float s8f(uint32_t w, int byte) {
 // 1/256 scale is applied later.  (-1)^n is applied here as a negation of odd
 // columns (row strides are even), which the compiler folds into the neg
 // modifiers of the first butterflies.
-template <int IN, int C>
+// SIGNED = false leaves the (-1)^n out (the frequency-shifted path folds it into its phasors).
+template <int IN, int C, bool SIGNED = true>
 __device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t xormask, int j0, cf *dst) {
     if constexpr (IN == IN_F32) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) dst[c] = ((j0 + c) & 1) ? -raw.w[c] : raw.w[c];
+        for (int c = 0; c < C; ++c) dst[c] = (SIGNED && ((j0 + c) & 1)) ? -raw.w[c] : raw.w[c];
     } else if constexpr (C == 1) {
         const uint32_t w = (uint32_t)raw.w ^ xormask;
         const cf z = cf{s8f(w, 0), s8f(w, 1)};
-        dst[0] = (j0 & 1) ? -z : z;
+        dst[0] = (SIGNED && (j0 & 1)) ? -z : z;
     } else {
         uint32_t words[C / 2];
         if constexpr (C == 2) {
@@ -385,7 +391,8 @@ __device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t x
         for (int q = 0; q < C / 2; ++q) {
             const uint32_t w = words[q] ^ xormask;
             dst[2 * q] = cf{s8f(w, 0), s8f(w, 1)};         // even column: +
-            dst[2 * q + 1] = -cf{s8f(w, 2), s8f(w, 3)};    // odd column: -
+            const cf odd = cf{s8f(w, 2), s8f(w, 3)};
+            dst[2 * q + 1] = SIGNED ? -odd : odd;          // odd column: -
         }
     }
 }
@@ -395,8 +402,27 @@ __device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t x
 // ---------------------------------------------------------------------------
 // MODE_T >= 0 fixes the epilogue at compile time (the hot MAG path); MODE_T = -1
 // dispatches on args.mode at run time (uniform branch).
-template <class Cfg, int IN, int MODE_T = -1>
+// e^{2 pi i turns}: the argument is reduced to [0, 1) in double; the f64 form is used once per
+// lane (prologue), the f32 form once per frame.
+__device__ __forceinline__ cf turn_phasor_f64(double turns) {
+    turns -= floor(turns);
+    double s, c;
+    sincospi(2.0 * turns, &s, &c);
+    return cf{(float)c, (float)s};
+}
+__device__ __forceinline__ cf turn_phasor_f32(double turns) {
+    turns -= floor(turns);
+    float s, c;
+    sincospif(2.0f * (float)turns, &s, &c);
+    return cf{c, s};
+}
+
+// ROT: u8 input is multiplied by a running phasor before the transform (nrf_freq_shifter fused
+// into the load, src/nrf.c:843-866): x[n] = (-1)^n (u8/256) e^{2 pi i (phase0 + m delta)}, with
+// the shifter's + 0.5 (1+i) restored like the offset-binary DC, analytically in bin N/2.
+template <class Cfg, int IN, int MODE_T = -1, bool ROT = false>
 struct FftKernel {
+    static_assert(!ROT || IN == IN_U8, "the fused frequency shift is a u8-input path");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
     static constexpr int LAST = NP - 1;
     static constexpr int R0 = Cfg::R(0), C0 = Cfg::C(0);
@@ -790,6 +816,18 @@ struct FftKernel {
             }
         }
 
+        // Fused frequency shift: this lane's samples are n = C0 t + c + r N/R0, so their phasors
+        // factor as (frame phase) x ebase[c] x rot_row[r]; ebase also carries (-1)^n (N/R0 is even).
+        cf ebase[ROT ? C0 : 1];
+        if constexpr (ROT) {
+#pragma unroll
+            for (int c = 0; c < C0; ++c) {
+                const unsigned n0 = (unsigned)(C0 * t + c);
+                const cf e = turn_phasor_f64(a.rot_delta * (double)n0);
+                ebase[c] = (n0 & 1u) ? -e : e;
+            }
+        }
+
         // A workgroup whose static unit does not exist still has to look for work (another
         // pool may be long): resolve its first ticket synchronously.
         unsigned par = 0;
@@ -832,8 +870,28 @@ struct FftKernel {
             // A lane without a frame (ragged last unit) still runs the barriers; it simply
             // transforms the zeros its loads returned and its stores are dropped.
             cf v[P];
+            if constexpr (ROT) {
+                // phase of the frame's first sample: reduced in double, evaluated in float (a common
+                // factor of the whole frame, so its rounding cannot disturb the spectrum's shape)
+                const size_t first = (u * FPW + (size_t)slot) * a.hop;
+                const cf ef = turn_phasor_f32(a.rot_phase0 + a.rot_delta * (double)first);
+                cf fr[C0];
 #pragma unroll
-            for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
+                for (int c = 0; c < C0; ++c) fr[c] = pk_cmul(ebase[c], ef);
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    convert_row<IN, C0, false>(raw[r], a.xormask, C0 * t, v + r * C0);
+                    const cf wr = a.rot_row[r];
+#pragma unroll
+                    for (int c = 0; c < C0; ++c) {
+                        // u8 = (u8 - 128) + 128: the shifter rotates the offset-binary value itself
+                        v[r * C0 + c] = pk_cmul(v[r * C0 + c] + cf{128.0f, 128.0f}, pk_cmul_uniform(fr[c], wr));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
+            }
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
             if constexpr (LAZY_SYNC) lazy_sync();  // the previous frame's last read is complete everywhere

@@ -22,6 +22,14 @@ __device__ __forceinline__ cf pk_cmul(cf a, cf w) {
     return t;
 }
 
+// a * w with a wavefront-uniform w held in an SGPR pair (one constant-bus operand per instruction).
+__device__ __forceinline__ cf pk_cmul_uniform(cf a, cf w) {
+    cf t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(a), "s"(w));
+    return t;
+}
+
 // c + a * w with the same two-instruction shape (the product's first half takes c as addend).
 __device__ __forceinline__ cf pk_cmul_add(cf a, cf w, cf c) {
     cf t;

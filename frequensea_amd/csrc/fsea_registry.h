@@ -18,9 +18,11 @@ struct KernelEntry {
     const void *fn_u8_mag; // __global__ function addresses (occupancy queries)
     const void *fn_u8;
     const void *fn_f32;
+    const void *fn_u8_rot; // u8 input with the fused frequency shift
     const char *name_u8_mag; // symbol names as rocprof shows them
     const char *name_u8;
     const char *name_f32;
+    const char *name_u8_rot;
     void (*launch)(int in_kind, const FftArgs &args, unsigned grid, hipStream_t stream);
 };
 
@@ -29,7 +31,7 @@ struct KernelEntry {
 
 }  // namespace fsea
 
-// Defines the two __global__ entry points (u8 IQ / f32 complex input) of one
+// Defines the __global__ entry points (u8 IQ: MAG / any mode / frequency-shifted; f32 complex) of one
 // configuration, with plain C names so that profiles are easy to read, and the
 // launch trampoline + KernelEntry for it.
 #define FSEA_DEFINE_KERNEL(NAME, VARIANT, ...)  /* NAME: C symbol stem; VARIANT: registry key */                                                        \
@@ -49,8 +51,15 @@ struct KernelEntry {
         __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
         fsea::FftKernel<NAME##_cfg, fsea::IN_F32>::run(a, lds);                                       \
     }                                                                                                 \
+    extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_u8_rot(      \
+        fsea::FftArgs a) {                                                                            \
+        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
+        fsea::FftKernel<NAME##_cfg, fsea::IN_U8, -1, true>::run(a, lds);                              \
+    }                                                                                                 \
     static void NAME##_launch(int in_kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {    \
-        if (in_kind == fsea::IN_U8 && a.mode == fsea::MODE_MAG) {                                     \
+        if (in_kind == fsea::IN_U8_ROT) {                                                             \
+            hipLaunchKernelGGL(NAME##_u8_rot, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);             \
+        } else if (in_kind == fsea::IN_U8 && a.mode == fsea::MODE_MAG) {                              \
             hipLaunchKernelGGL(NAME##_u8_mag, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);             \
         } else if (in_kind == fsea::IN_U8) {                                                          \
             hipLaunchKernelGGL(NAME##_u8, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);                 \
@@ -72,8 +81,10 @@ struct KernelEntry {
         reinterpret_cast<const void *>(&NAME##_u8_mag),                                               \
         reinterpret_cast<const void *>(&NAME##_u8),                                                   \
         reinterpret_cast<const void *>(&NAME##_f32),                                                  \
+        reinterpret_cast<const void *>(&NAME##_u8_rot),                                               \
         #NAME "_u8_mag",                                                                              \
         #NAME "_u8",                                                                                  \
         #NAME "_f32",                                                                                 \
+        #NAME "_u8_rot",                                                                              \
         &NAME##_launch};                                                                              \
     }

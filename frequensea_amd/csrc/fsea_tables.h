@@ -53,4 +53,16 @@ inline void build_twiddles(int np, const int *radix, std::vector<TwPair> &tw, si
     for (int i = np; i < 4; ++i) offsets[i] = tw.size();
 }
 
+// Fused frequency shift (FftArgs::rot_row): the phasor between consecutive pass-0 rows of one
+// lane, rows[r] = e^{2 pi i delta r n / r0}, delta in turns per sample; 32 entries (r0 <= 32).
+inline void build_rotation_rows(int n, int r0, double delta, TwPair *rows) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int r = 0; r < 32; ++r) {
+        double turns = (r < r0) ? delta * (double)r * (double)(n / r0) : 0.0;
+        turns -= std::floor(turns);
+        rows[r].re = (float)std::cos(two_pi * turns);
+        rows[r].im = (float)std::sin(two_pi * turns);
+    }
+}
+
 }  // namespace fsea

@@ -23,7 +23,7 @@ _MODE_DTYPE = {
 EXPORTS = [
     "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_create_variant",
     "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device",
-    "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_mean_magnitude_u8_device",
+    "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_exec_u8_shifted_device", "fsea_exec_u8_shifted_host", "fsea_mean_magnitude_u8_device",
     "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
     "fsea_copy_to_host", "fsea_stream_synchronize", "fsea_time_exec_u8_device",
     "fsea_plan_kernel_name", "fsea_last_error_string", "fsea_plan_read_trace",
@@ -72,6 +72,8 @@ def hip_lib():
         L.fsea_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp]
         L.fsea_exec_u8_host.argtypes = [vp, vp, sz, ci, vp]
         L.fsea_exec_f64_host.argtypes = [vp, vp, sz, vp]
+        L.fsea_exec_u8_shifted_device.argtypes = [vp, vp, sz, ci, ctypes.c_double, ctypes.c_double, vp, vp]
+        L.fsea_exec_u8_shifted_host.argtypes = [vp, vp, sz, ci, ctypes.c_double, ctypes.c_double, vp]
         L.fsea_mean_magnitude_u8_device.argtypes = [vp, vp, sz, ci, ctypes.POINTER(ctypes.c_double), vp]
         L.fsea_composite_max_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 6 + [ci, vp]
         L.fsea_stitch_tiles_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 6 + [ci, vp]
@@ -165,6 +167,21 @@ class Plan:
             raise ValueError("iq too short for %d frames" % n_frames)
         out = np.empty((n_frames, self.fft_size), dtype=self.out_dtype)
         _check(self._L.fsea_exec_u8_host(self._p, iq.ctypes.data, n_frames, int(bool(flip)), out.ctypes.data))
+        return out
+
+    def exec_shifted_device(self, d_iq_ptr, n_frames, d_out_ptr, cycles_per_sample, phase0_cycles=0.0, flip=True,
+                            stream=0):
+        """fsea_exec_u8_shifted_device: the frequency shifter fused into the FFT's load."""
+        _check(self._L.fsea_exec_u8_shifted_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), cycles_per_sample,
+                                                   phase0_cycles, d_out_ptr, stream or None))
+
+    def exec_shifted_host(self, iq_u8, n_frames, cycles_per_sample, phase0_cycles=0.0, flip=True):
+        iq = np.ascontiguousarray(iq_u8, dtype=np.uint8).ravel()
+        if iq.size < self.in_bytes(n_frames):
+            raise ValueError("iq too short for %d frames" % n_frames)
+        out = np.empty((n_frames, self.fft_size), dtype=self.out_dtype)
+        _check(self._L.fsea_exec_u8_shifted_host(self._p, iq.ctypes.data, n_frames, int(bool(flip)),
+                                                 cycles_per_sample, phase0_cycles, out.ctypes.data))
         return out
 
     def exec_host_f64(self, iq_f64, n_frames):

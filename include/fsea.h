@@ -14,6 +14,9 @@
  *                         c/fft-batch.c:62-69, 83-94; c/fft-batch-broad.c:64-71,
  *                         106-121
  *   fsea_exec_f64_host    the NUT_BUFFER_F64 input branch, src/nrf.c:607-609
+ *   fsea_exec_u8_shifted_* nrf_freq_shifter_process in front of the FFT, fused into its load
+ *                         src/nrf.c:843-866 (shifter) + 607-612 (F64 branch);
+ *                         call pattern lua/fft-shifted.lua:52-55
  *   fsea_mean_magnitude_* the 100-row "interesting?" gate,
  *                         c/fft-batch-broad.c:81-98
  *   fsea_composite_max_*  tile compositing, c/fft-stitch.c:46-54,
@@ -104,6 +107,21 @@ int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int 
  * returns when `out` is complete. */
 int fsea_exec_u8_host(fsea_plan *plan, const uint8_t *iq, size_t n_frames, int flip,
                       void *out);
+
+/* Frequency-shifted spectrum, the device-resident form of
+ *   nrf_freq_shifter_process(shifter, samples); nrf_fft_process(fft, shifter_buffer)
+ * (src/nrf.c:843-866, 598-631; lua/fft-shifted.lua:52-55) with the rotation fused into the FFT
+ * kernel's load.  Stream sample m (frame f, sample n: m = f*hop + n) becomes
+ *   y[m] = (u8[m] / 256) * e^{+2 pi i (phase0_cycles + m * cycles_per_sample)} + 0.5 (1 + i)
+ * and frame f transforms x[n] = (-1)^n y[f*hop + n]; epilogue per the plan's mode.
+ * cycles_per_sample = freq_offset / sample_rate; phase0_cycles continues a stream across calls
+ * (a shifter that has consumed M samples is at phase M * cycles_per_sample).  Other arguments
+ * as fsea_exec_u8_device / fsea_exec_u8_host. */
+int fsea_exec_u8_shifted_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
+                                double cycles_per_sample, double phase0_cycles, void *d_out,
+                                void *stream);
+int fsea_exec_u8_shifted_host(fsea_plan *plan, const uint8_t *iq, size_t n_frames, int flip,
+                              double cycles_per_sample, double phase0_cycles, void *out);
 
 /* F64 interleaved complex input (src/nrf.c:607-609: no /256, no flip). */
 int fsea_exec_f64_host(fsea_plan *plan, const double *iq, size_t n_frames, void *out);

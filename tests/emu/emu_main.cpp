@@ -28,8 +28,13 @@ unsigned emu_readfirstlane(unsigned v) {
     return r;
 }
 
-template <class Cfg, int IN, int MODE_T>
+template <class Cfg, int IN, int MODE_T, bool ROT = false>
 static void run_grid(fsea::FftArgs a, unsigned grid) {
+    if (ROT) {
+        fsea::TwPair rows[32];
+        fsea::build_rotation_rows(Cfg::N, Cfg::R(0), a.rot_delta, rows);
+        for (int r = 0; r < 32; ++r) a.rot_row[r] = fsea::cf{rows[r].re, rows[r].im};
+    }
     std::vector<fsea::TwPair> tw;
     size_t off[5];
     const int radix[4] = {Cfg::R(0), Cfg::R(1), Cfg::R(2), Cfg::R(3)};
@@ -59,7 +64,7 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
                 g_barrier = &bar;
                 g_wave_barrier = wbar[t / 64].get();
                 g_wave_slot = &wslot[t / 64];
-                fsea::FftKernel<Cfg, IN, MODE_T>::run(a, lds);
+                fsea::FftKernel<Cfg, IN, MODE_T, ROT>::run(a, lds);
             });
         }
         for (auto &x : th) x.join();
@@ -72,7 +77,8 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
 
 template <class Cfg>
 static int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsigned grid) {
-    if (in_kind == fsea::IN_U8 && mode_t == 0) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
+    if (in_kind == fsea::IN_U8_ROT) run_grid<Cfg, fsea::IN_U8, -1, true>(a, grid);
+    else if (in_kind == fsea::IN_U8 && mode_t == 0) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
     else if (in_kind == fsea::IN_U8) run_grid<Cfg, fsea::IN_U8, -1>(a, grid);
     else run_grid<Cfg, fsea::IN_F32, -1>(a, grid);
     return 0;
@@ -88,9 +94,19 @@ extern "C" int emu_fft(int n, int in_kind, int specialised, const void *in, void
     return emu_fft_variant(n, "", in_kind, specialised, in, out, n_frames, hop, flip, mode, grid);
 }
 
+static double g_rot_delta = 0.0, g_rot_phase0 = 0.0;
+
+// in_kind 2 (frequency-shifted u8 input) takes its shift from here
+extern "C" void emu_set_shift(double cycles_per_sample, double phase0_cycles) {
+    g_rot_delta = cycles_per_sample;
+    g_rot_phase0 = phase0_cycles;
+}
+
 extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int specialised, const void *in, void *out,
                                size_t n_frames, size_t hop, int flip, int mode, unsigned grid) {
     fsea::FftArgs a;
+    a.rot_delta = g_rot_delta;
+    a.rot_phase0 = g_rot_phase0;
     a.in = in;
     a.out = out;
     a.n_frames = n_frames;

@@ -13,6 +13,8 @@ static inline cf pk_cmul(cf a, cf w) {
     return t;
 }
 
+static inline cf pk_cmul_uniform(cf a, cf w) { return pk_cmul(a, w); }
+
 static inline cf pk_cmul_add(cf a, cf w, cf c) {
     cf t = cf{fmaf(a[0], w[0], c[0]), fmaf(a[1], w[0], c[1])};
     t = cf{fmaf(-a[1], w[1], t[0]), fmaf(a[0], w[1], t[1])};

@@ -93,5 +93,13 @@ static inline unsigned long long wall_clock64() { return 0; }
 #define __builtin_readcyclecounter() 0ull
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
+static inline void sincospi(double x, double *s, double *c) {
+    *s = sin(3.14159265358979323846 * x);
+    *c = cos(3.14159265358979323846 * x);
+}
+static inline void sincospif(float x, float *s, float *c) {
+    *s = sinf(3.14159265358979323846f * x);
+    *c = cosf(3.14159265358979323846f * x);
+}
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x)
 #define __builtin_amdgcn_logf(x) log2f(x)

@@ -45,8 +45,14 @@ def emu_lib():
     return _EMU
 
 
-def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0, variant=""):
+def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0, variant="",
+             shift=None):
+    """shift = (cycles_per_sample, phase0_cycles) selects the frequency-shifted u8 kernel (in_kind 2)."""
     hop = n if hop is None else hop
+    if shift is not None:
+        in_kind = 2
+        emu_lib().emu_set_shift.argtypes = [ctypes.c_double, ctypes.c_double]
+        emu_lib().emu_set_shift(float(shift[0]), float(shift[1]))
     src = np.ascontiguousarray(iq)
     out = np.zeros((n_frames, n), dtype=OUT_DTYPE[mode])
     rc = emu_lib().emu_fft_variant(n, variant.encode(), in_kind, int(specialised), src.ctypes.data,

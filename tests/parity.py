@@ -56,3 +56,15 @@ def check_mode(got, iq, n, n_frames, hop, flip, mode):
     if mode == 5:
         return check_db(got, want, O.rows(iq, n_frames, n, hop=hop, flip=flip, mode=O.MODE_MAG_NODC))
     return check_float(got, want)
+
+
+def check_mode_shifted(got, iq, n, n_frames, hop, flip, mode, cycles_per_sample, phase0_cycles=0.0):
+    """check_mode for the frequency-shifted path (oracle: orc_rows_shifted)."""
+    kw = dict(hop=hop, flip=flip)
+    want = O.rows_shifted(iq, n_frames, n, cycles_per_sample, phase0_cycles, mode=ORACLE_MODE[mode], **kw)
+    if mode in (1, 2):
+        return check_u8(got, want)
+    if mode == 5:
+        return check_db(got, want, O.rows_shifted(iq, n_frames, n, cycles_per_sample, phase0_cycles,
+                                                  mode=O.MODE_MAG_NODC, **kw))
+    return check_float(got, want)

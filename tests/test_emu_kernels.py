@@ -131,3 +131,23 @@ def test_random_geometry_sweep():
             parity.check_mode(got, iq, n, nf, hop, flip, mode)
         except AssertionError as e:
             raise AssertionError("n=%d hop=%d nf=%d mode=%d flip=%s grid=%d: %s" % (n, hop, nf, mode, flip, grid, e))
+
+
+@pytest.mark.parametrize("n", [128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_frequency_shifted_input(n):
+    """The ROT kernels (fsea_exec_u8_shifted_*): nrf_freq_shifter fused into the load, against
+    the oracle's shifter + F64-branch FFT.  150 kHz at 5 Msps as lua/fft-shifted.lua would ask."""
+    nf = 5 if n <= 2048 else 3
+    iq = synth_iq(500 + n, 2 * nf * n)
+    delta, phase0 = 150000 / 5000000, 0.3125
+    for mode in (0, 3, 1):
+        got = emu_rows(iq, n, nf, mode=mode, grid=2, shift=(delta, phase0))
+        parity.check_mode_shifted(got, iq, n, nf, n, True, mode, delta, phase0)
+
+
+def test_frequency_shift_overlap_negative_offset_and_no_flip():
+    n, hop, nf = 1024, 256, 9
+    iq = synth_iq(77, 2 * ((nf - 1) * hop + n))
+    for delta, flip in ((-0.123456789, True), (0.49, False), (0.0, True), (7.25, True)):
+        got = emu_rows(iq, n, nf, hop=hop, flip=flip, mode=3, grid=3, shift=(delta, 0.0))
+        parity.check_mode_shifted(got, iq, n, nf, hop, flip, 3, delta, 0.0)

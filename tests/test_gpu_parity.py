@@ -401,3 +401,103 @@ def test_block_graph_device_to_fft(tmp_path):
     assert hist[0].any()
     parity.check_float(hist[0], want)
     L.nrf_fft_free(fft)
+
+
+# ---------------------------------------------------------------------------------------------
+# frequency shifter in front of the FFT (src/nrf.c:843-866; lua/fft-shifted.lua:52-55)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", SIZES)
+def test_frequency_shifted_rows_all_sizes(n):
+    """fsea_exec_u8_shifted_host: the shifter fused into the FFT kernel's load vs the oracle's
+    shifter -> F64-branch FFT.  150 kHz at 5 Msps, the step lua/fft-shifted.lua works in."""
+    nf = 150 if n <= 1024 else 21
+    iq = synth_iq(600 + n, 2 * nf * n)
+    delta, phase0 = 150000 / 5000000, 0.8125
+    for mode in (0, 3, 1, 5):
+        plan = fsea.Plan(n, mode=mode)
+        got = plan.exec_shifted_host(iq, nf, delta, phase0)
+        parity.check_mode_shifted(got, iq, n, nf, n, True, mode, delta, phase0)
+        plan.close()
+
+
+@pytest.mark.parametrize("n,hop,delta,flip", [(1024, 256, -0.123456789, True), (4096, 2048, 0.49, False),
+                                              (8192, 8192, 0.0, True), (16384, 8192, 7.25, True),
+                                              (256, 8, 1e-7, True)])
+def test_frequency_shift_geometry_and_sign(n, hop, delta, flip):
+    nf = 11
+    iq = synth_iq(700 + n, 2 * ((nf - 1) * hop + n))
+    plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_COMPLEX_F32)
+    got = plan.exec_shifted_host(iq, nf, delta, 0.0, flip=flip)
+    parity.check_mode_shifted(got, iq, n, nf, hop, flip, 3, delta, 0.0)
+    plan.close()
+
+
+def test_frequency_shift_by_whole_bins_rolls_the_spectrum_at_full_size():
+    """Size-independent property at the BASELINE batch (8192 points, 4096 frames): shifting by
+    k bins rotates the unshifted complex spectrum by k and adds the shifter's 0.5 (1+i) to bin N/2;
+    a stream continued with phase0 equals the same stream processed in one call."""
+    n, nf, k = 8192, 4096, 1237
+    iq = synth_iq(3, 2 * nf * n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_a, d_b = DeviceBuffer(nf * n * 8), DeviceBuffer(nf * n * 8)
+    plan = fsea.Plan(n, mode=fsea.MODE_COMPLEX_F32)
+    plan.exec_device(d_in.ptr, nf, d_a.ptr)
+    plan.exec_shifted_device(d_in.ptr, nf, d_b.ptr, k / n)
+    plan.synchronize()
+    rows = np.unique(np.r_[0, 1, nf - 1, np.random.default_rng(9).integers(0, nf, 40)])
+    plain = d_a.download(np.complex64, (nf, n))[rows].astype(np.complex128)
+    shifted = d_b.download(np.complex64, (nf, n))[rows].astype(np.complex128)
+    want = np.roll(plain, k, axis=1)
+    want[:, n // 2] += 0.5 * n * (1 + 1j) - 0.0
+    # the unshifted path restores its own offset-binary DC in bin n/2; after the roll that sits in
+    # bin n/2 + k, exactly where the shifter moves it
+    err = np.linalg.norm(shifted - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() < 1e-6, err.max()
+    # second half of the batch as a continued stream: phase0 = samples consumed * cycles per sample
+    half = nf // 2
+    delta = 150000 / 5000000
+    plan.exec_shifted_device(d_in.ptr, nf, d_a.ptr, delta)
+    plan.exec_shifted_device(d_in.ptr.value + 2 * half * n, nf - half, d_b.ptr, delta, (half * n) * delta)
+    plan.synchronize()
+    whole = d_a.download(np.complex64, (nf, n))[half:]
+    cont = d_b.download(np.complex64, (nf, n))[: nf - half]
+    err = np.linalg.norm(whole - cont, axis=1) / np.linalg.norm(whole, axis=1)
+    assert err.max() < 1e-6, err.max()
+    for f in (0, nf - half - 1):
+        want = O.rows_shifted(iq[2 * (half + f) * n: 2 * (half + f + 1) * n], 1, n, delta, ((half + f) * n) * delta,
+                              mode=O.MODE_COMPLEX)[0]
+        parity.check_float(cont[f], want)
+    for b in (d_in, d_a, d_b):
+        b.free()
+    plan.close()
+
+
+def test_lua_fft_shifted_call_chain(tmp_path):
+    """lua/fft-shifted.lua:52-55 through the reference-shaped C API: device block -> nrf_freq_shifter
+    (host, f64) -> nrf_fft (GPU, F64 input branch); and the same rows from the fused device path."""
+    L = nrf.nrf_lib()
+    raw = synth_iq(41, 2 * nrf.NRF_BUFFER_SIZE_BYTES)
+    blocks = (raw ^ np.uint8(0x80)).reshape(2, -1)
+    n, h, off, fs = 1024, 16, 150000, 5000000
+    fft = L.nrf_fft_new(n, h)
+    sh = L.nrf_freq_shifter_new(off, fs)
+    for blk in blocks:
+        buf = L.nut_buffer_new_u8(nrf.NRF_SAMPLES_LENGTH, 2, blk.ctypes.data)
+        L.nrf_freq_shifter_process(sh, buf)
+        shifted = L.nrf_freq_shifter_get_buffer(sh)
+        L.nrf_fft_process(fft, shifted)
+        L.nut_buffer_free(shifted)
+        L.nut_buffer_free(buf)
+    out = L.nrf_fft_get_buffer(fft)
+    hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+    L.nut_buffer_free(out)
+    L.nrf_freq_shifter_free(sh)
+    L.nrf_fft_free(fft)
+    plan = fsea.Plan(n)
+    for b, blk in enumerate(blocks):
+        phase0 = b * nrf.NRF_SAMPLES_LENGTH * (off / fs)          # what the shifter's state amounts to
+        want = O.rows_shifted(blk[: 2 * n], 1, n, off / fs, phase0, flip=False)[0]
+        parity.check_float(hist[1 - b], want)                     # newest row first
+        fused = plan.exec_shifted_host(blk[: 2 * n], 1, off / fs, phase0, flip=False)[0]
+        parity.check_float(fused, want)
+    plan.close()
