@@ -786,19 +786,35 @@ struct FftKernel {
         if constexpr (DYNAMIC) {
             u = (size_t)pools.start(cur) + b / POOLS;         // static first unit
             if (u >= pools.start(cur + 1)) u = n_units;       // more workgroups than units in this pool
-            if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+        }
+        // the table block's loads go first: they mostly hit L2 / the Infinity Cache, and loads
+        // return in order, so behind unit 0's bytes (HBM) they would only be usable when those are
+        constexpr int TAB_COPY = (Cfg::TWL || Cfg::TWR) ? Cfg::TAB_SMALL : 0;
+        constexpr int TAB_REGS = (TAB_COPY + Cfg::WG - 1) / Cfg::WG;
+        cf tabv[TAB_REGS > 0 ? TAB_REGS : 1];
+#pragma unroll
+        for (int i = 0; i < TAB_REGS; ++i) {
+            const int e = tid + i * Cfg::WG;
+            tabv[i] = a.tw_small[e < TAB_COPY ? e : TAB_COPY - 1];  // clamped, not predicated: no branch
         }
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+        if constexpr (DYNAMIC) {
+            if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
+        }
 
         // The small twiddle block (middle-pass tables + HI/LO factors, a few KiB) goes to LDS, and
         // the last pass's register-resident twiddles W^{r k}, k = CL t + c, are built from the
         // two factor tables: W^{m} = HI[m >> 6] * LO[m & 63].  (Loading those (RL-1) CL twiddles
         // per lane from the full table instead cost 32 MB of L2 traffic per launch and a
         // 5.8 us prologue.)  All of it overlaps the latency of unit 0's bytes requested above.
-        constexpr int TAB_COPY = (Cfg::TWL || Cfg::TWR) ? Cfg::TAB_SMALL : 0;
         if constexpr (TAB_COPY > 0) {
-            for (int e = tid; e < TAB_COPY; e += Cfg::WG) lds_all[FPW * Cfg::LDS_FRAME + e] = a.tw_small[e];
+#pragma unroll
+            for (int i = 0; i < TAB_REGS; ++i) {
+                const int e = tid + i * Cfg::WG;
+                // lanes past the end rewrite the last entry with its own value (loaded clamped above)
+                lds_all[FPW * Cfg::LDS_FRAME + (e < TAB_COPY ? e : TAB_COPY - 1)] = tabv[i];
+            }
             __syncthreads();
         }
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
