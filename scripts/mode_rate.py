@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Steady-state rate of every epilogue mode (run-time-mode kernel `*_u8`, and the compile-time MAG
+kernel) on resident data.  Usage: python scripts/mode_rate.py [N ...]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from frequensea_amd import fsea  # noqa: E402
+
+TOTAL_SAMPLES = 1 << 27
+NAMES = {0: "MAG_F32", 1: "DB10_U8", 2: "DB5_U8_DCFIX", 3: "COMPLEX_F32", 4: "MAG_NODC_F32", 5: "DB_F32"}
+OUT_BYTES = {0: 4, 1: 1, 2: 1, 3: 8, 4: 4, 5: 4}
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [1024, 4096, 8192]
+    L = fsea.hip_lib()
+    rng = np.random.default_rng(1)
+    host = rng.integers(-70, 70, 2 * TOTAL_SAMPLES, dtype=np.int8).view(np.uint8)
+    d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    fsea._check(L.fsea_device_alloc(0, host.nbytes, ctypes.byref(d_in)))
+    fsea._check(L.fsea_device_alloc(0, 8 * TOTAL_SAMPLES, ctypes.byref(d_out)))
+    fsea._check(L.fsea_copy_to_device(0, d_in, host.ctypes.data, host.nbytes))
+    for n in sizes:
+        frames = TOTAL_SAMPLES // n
+        for mode in range(6):
+            plan = fsea.Plan(n, mode=mode)
+            plan.time_device(d_in, frames, d_out, 20)
+            ms = sorted(plan.time_device(d_in, frames, d_out, 10) for _ in range(5))[2]
+            bytes_ = frames * n * (2 + OUT_BYTES[mode])
+            print("N=%-6d %-13s %-24s %7.3f ms %8.1f Mframes/s %8.1f Gsamples/s %7.1f GB/s %5.1f%% of 8 TB/s" %
+                  (n, NAMES[mode], plan.kernel_name, ms, frames / ms / 1e3, frames * n / ms / 1e6,
+                   bytes_ / ms / 1e6, bytes_ / ms / 1e6 / 80))
+            plan.close()
+
+
+if __name__ == "__main__":
+    main()
