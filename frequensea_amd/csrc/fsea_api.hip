@@ -256,8 +256,8 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.tw_small = p->d_tw;
     const int occ = (in_kind == fsea::IN_F32)      ? p->occ_f32
                     : (in_kind == fsea::IN_U8_ROT) ? p->occ_u8_rot
-                    : (mode == FSEA_MODE_MAG_F32)  ? p->occ_u8_mag
-                                                   : p->occ_u8;
+                    : (mode == FSEA_MODE_MAG_F32 && flip) ? p->occ_u8_mag  // the kernel the trampoline picks
+                                                          : p->occ_u8;
     p->entry->launch(in_kind, a, grid_for(p, occ, n_frames), s);
     FSEA_HIP(hipGetLastError());
     return FSEA_OK;

@@ -771,6 +771,9 @@ struct FftKernel {
         }
 
         const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
+        // the compile-time MAG kernel is the raw-int8 (HackRF, flip) path: its bytes are the signed
+        // samples already, no XOR; offset-binary input goes through the run-time-mode kernel
+        const uint32_t xormask = (MODE_T == MODE_MAG) ? 0u : a.xormask;
         const uint32_t esz = elem_bytes(mode);
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
         const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
@@ -906,7 +909,7 @@ struct FftKernel {
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], a.xormask, C0 * t, v + r * C0);
+                for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], xormask, C0 * t, v + r * C0);
             }
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);

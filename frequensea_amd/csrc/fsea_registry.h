@@ -59,7 +59,7 @@ struct KernelEntry {
     static void NAME##_launch(int in_kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {    \
         if (in_kind == fsea::IN_U8_ROT) {                                                             \
             hipLaunchKernelGGL(NAME##_u8_rot, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);             \
-        } else if (in_kind == fsea::IN_U8 && a.mode == fsea::MODE_MAG) {                              \
+        } else if (in_kind == fsea::IN_U8 && a.mode == fsea::MODE_MAG && a.xormask == 0) {            \
             hipLaunchKernelGGL(NAME##_u8_mag, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);             \
         } else if (in_kind == fsea::IN_U8) {                                                          \
             hipLaunchKernelGGL(NAME##_u8, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);                 \

@@ -114,7 +114,7 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
     a.trace = nullptr;
-    const int mt = (specialised && mode == fsea::MODE_MAG && in_kind == fsea::IN_U8) ? 0 : -1;
+    const int mt = (specialised && mode == fsea::MODE_MAG && in_kind == fsea::IN_U8 && flip) ? 0 : -1;
     const std::string v = variant ? variant : "";
     if (!v.empty()) {
 #define EMU_VARIANT(NN, NAME, CFG) \
