@@ -501,3 +501,43 @@ def test_lua_fft_shifted_call_chain(tmp_path):
         fused = plan.exec_shifted_host(blk[: 2 * n], 1, off / fs, phase0, flip=False)[0]
         parity.check_float(fused, want)
     plan.close()
+
+
+@pytest.mark.parametrize("n", [1024, 8192])
+def test_batches_beyond_4_gib(n):
+    """Maximum sizes: one launch whose input (4.5 GiB) and output (9 GiB) both cross 32-bit byte
+    offsets (static frame interleave at 1024, ticket pools at 8192).  The kernel rebases a 64-bit
+    buffer window per unit; rows on either side of every 4 GiB boundary, the first and the last are
+    compared with the oracle."""
+    chunk_frames = (1 << 25) // n                            # 64 MiB of IQ per host chunk
+    n_chunks = 72
+    nf = chunk_frames * n_chunks                             # 4.5 GiB in, 9 GiB out
+    L = fsea.hip_lib()
+    chunk = synth_iq(4242, 2 * chunk_frames * n)
+    d_in = DeviceBuffer(chunk.nbytes * n_chunks)
+    d_out = DeviceBuffer(nf * n * 4)
+    for k in range(n_chunks):                                # the same 64 MiB repeated; frame f = chunk frame f % 32768
+        fsea._check(L.fsea_copy_to_device(0, ctypes.c_void_p(d_in.ptr.value + k * chunk.nbytes),
+                                          chunk.ctypes.data, chunk.nbytes))
+    plan = fsea.Plan(n)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    in_edge = (1 << 32) // (2 * n)                           # first frame past 4 GiB of input
+    out_edges = [(1 << 32) // (4 * n), (2 << 32) // (4 * n)]  # first frames past 4 and 8 GiB of output
+    frames = sorted({0, 1, nf - 1, nf - 2, in_edge - 1, in_edge, in_edge + 1,
+                     *[e + d for e in out_edges for d in (-1, 0, 1)]})
+    row = np.empty(n, np.float32)
+    for f in frames:
+        fsea._check(L.fsea_copy_to_host(0, row.ctypes.data, ctypes.c_void_p(d_out.ptr.value + f * n * 4), n * 4))
+        g = f % chunk_frames
+        parity.check_float(row, O.rows(chunk[2 * g * n: 2 * (g + 1) * n], 1, n)[0])
+    # and a sample of rows against their periodic copies (every chunk holds the same frames)
+    a = np.empty((64, n), np.float32)
+    b = np.empty((64, n), np.float32)
+    fsea._check(L.fsea_copy_to_host(0, a.ctypes.data, ctypes.c_void_p(d_out.ptr.value + 100 * n * 4), a.nbytes))
+    fsea._check(L.fsea_copy_to_host(0, b.ctypes.data,
+                                    ctypes.c_void_p(d_out.ptr.value + (71 * chunk_frames + 100) * n * 4), b.nbytes))
+    assert np.array_equal(a, b)
+    d_in.free()
+    d_out.free()
+    plan.close()
