@@ -11,7 +11,7 @@
 #define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 14
 // multi-wave frames (4096: 16 points per lane, four workgroups per CU)
 #define FSEA_CFG_4096 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 10
-#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 14
+#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 30
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 8
 
 // ---- tuning variants (selected with fsea_plan_create_variant; not the defaults) ----

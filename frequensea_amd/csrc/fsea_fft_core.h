@@ -194,7 +194,11 @@ struct FftCfg {
     //     for them become progressive;
     // 4 = a middle pass fetches all its twiddles from LDS together with the data;
     // 8 = the twiddle multiply is fused into the first butterfly level (dft_regs_tw; one packed
-    //     op less per pair, rounding differs in the last bit).
+    //     op less per pair, rounding differs in the last bit);
+    // 16 = a middle pass that reads 16 bytes per lane (C = 2, P = 32) rotates its lanes inside every
+    //     16-lane block by the block index: the pad shifts each block by one 16-byte slot, which
+    //     puts two lanes of every ds_read_b128 lane group on one slot (8 instead of 4 LDS cycles
+    //     per instruction; scripts/lds_conflicts.py); rotated, the groups are conflict-free.
     static constexpr int OPT = OPT_;
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
@@ -441,6 +445,18 @@ struct FftKernel {
     static constexpr bool BATCH_READS = (Cfg::OPT & 2) != 0;
     static constexpr bool TW_HOIST = (Cfg::OPT & 4) != 0;
     static constexpr bool TW_FUSE = (Cfg::OPT & 8) != 0 && (Cfg::ABL & 4) == 0;
+    static constexpr bool LANE_ROT = (Cfg::OPT & 16) != 0;
+    // which frame-lane a physical lane works as in middle pass I (any bijection is valid: passes
+    // meet only through LDS, at logical addresses)
+    template <int I>
+    static __device__ __forceinline__ int pass_lane(int t) {
+        if constexpr (LANE_ROT && Cfg::C(I) == 2 && P == 32 && (T % 16) == 0) {
+            const int blk = t >> 4;
+            return (blk << 4) | ((t - blk) & 15);
+        } else {
+            return t;
+        }
+    }
     static __device__ __forceinline__ void after_reads() {
         if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
     }
@@ -594,9 +610,10 @@ struct FftKernel {
 
     // middle pass I (1 <= I < LAST): read, twiddle, DFT, write back
     template <int I>
-    static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t) {
+    static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t0) {
         if constexpr (I < LAST) {
             constexpr int R = Cfg::R(I), C = Cfg::C(I);
+            const int t = pass_lane<I>(t0);
             const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
             if constexpr (TW_HOIST && (Cfg::Ns(I) % C == 0)) {
                 constexpr int Ns = Cfg::Ns(I);
@@ -630,7 +647,7 @@ struct FftKernel {
             if constexpr (LAZY_SYNC) lazy_sync();  // same barrier, after this wave's butterflies
             lds_write<I>(lds, v, t);
             frame_sync();
-            middle_pass<I + 1>(lds, lds_all, v, a, t);
+            middle_pass<I + 1>(lds, lds_all, v, a, t0);
         }
     }
 
