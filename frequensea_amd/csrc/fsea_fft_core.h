@@ -445,18 +445,30 @@ struct FftKernel {
     static constexpr bool BATCH_READS = (Cfg::OPT & 2) != 0;
     static constexpr bool TW_HOIST = (Cfg::OPT & 4) != 0;
     static constexpr bool TW_FUSE = (Cfg::OPT & 8) != 0 && (Cfg::ABL & 4) == 0;
-    static constexpr bool LANE_ROT = (Cfg::OPT & 16) != 0;
-    // which frame-lane a physical lane works as in middle pass I (any bijection is valid: passes
-    // meet only through LDS, at logical addresses)
+    static constexpr bool LANE_ROT = (Cfg::OPT & 16) != 0;       // middle passes
+    static constexpr bool LANE_ROT_LAST = (Cfg::OPT & 32) != 0;  // the last pass as well
+    // Which frame-lane a physical lane works as in pass I >= 1.  Any bijection is valid: passes meet
+    // only through LDS, at logical addresses.  Two layouts need one (scripts/lds_conflicts.py):
+    // * 16 bytes per lane (C = 2, P = 32): the pad shifts each 16-lane block by one 16-byte slot and
+    //   the ds_read_b128 lane groups mix lanes of two blocks -> rotate block b by b;
+    // * 8 bytes per lane with P = 16 (the 4096-point passes): the pad shifts each block by two
+    //   8-byte units, so the two blocks of a 32-lane ds_read_b64 group overlap by two units ->
+    //   pair block b with block b + T/32 instead of b + 1.
     template <int I>
     static __device__ __forceinline__ int pass_lane(int t) {
-        if constexpr (LANE_ROT && Cfg::C(I) == 2 && P == 32 && (T % 16) == 0) {
+        constexpr bool ON = (I == LAST) ? LANE_ROT_LAST : LANE_ROT;
+        if constexpr (ON && Cfg::C(I) == 2 && P == 32 && (T % 16) == 0) {
             const int blk = t >> 4;
             return (blk << 4) | ((t - blk) & 15);
+        } else if constexpr (ON && Cfg::C(I) == 1 && P == 16 && T == 256) {
+            const int blk = t >> 4;
+            const int logical = (blk >> 1) | ((blk & 1) << 3);
+            return (logical << 4) | (t & 15);
         } else {
             return t;
         }
     }
+
     static __device__ __forceinline__ void after_reads() {
         if constexpr (BATCH_READS) __builtin_amdgcn_sched_barrier(0);
     }
@@ -795,7 +807,8 @@ struct FftKernel {
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
         const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
         const uint32_t in_voff = (uint32_t)IN_BPS * ((uint32_t)slot * (uint32_t)a.hop + (uint32_t)(C0 * t));
-        const uint32_t out_elem = (uint32_t)slot * (uint32_t)N + (uint32_t)(CL * t);
+        const int tl = pass_lane<LAST>(t);  // this lane's place in the last pass
+        const uint32_t out_elem = (uint32_t)slot * (uint32_t)N + (uint32_t)(CL * tl);
 
         // Prologue: every independent request is issued before the first wait, so that
         // the latencies overlap: the ticket for the second unit, unit 0's bytes (HBM
@@ -844,7 +857,7 @@ struct FftKernel {
             for (int r = 1; r < RL; ++r) {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
-                    const unsigned m = (unsigned)r * (unsigned)(CL * t + c);
+                    const unsigned m = (unsigned)r * (unsigned)(CL * tl + c);
                     cf w = pk_cmul(hi[m >> 6], lo[m & 63u]);
                     if constexpr (PRESCALED) w = w * cf{SC, SC};
                     twl[(r - 1) * CL + c] = w;
@@ -947,7 +960,7 @@ struct FftKernel {
             middle_pass<1>(lds, lds_all, v, a, t);
 
             // last pass
-            lds_read<LAST>(lds, v, t);
+            lds_read<LAST>(lds, v, tl);
             after_reads();
             if constexpr (!LAZY_SYNC) frame_sync();  // the buffer is free for the next frame's pass 0
             if constexpr (Cfg::TWR && TW_FUSE) {
@@ -967,13 +980,13 @@ struct FftKernel {
                     }
                 }
             } else {
-                apply_twiddles<LAST>(v, a.tw[LAST], t);
+                apply_twiddles<LAST>(v, a.tw[LAST], tl);
             }
             if constexpr (!(Cfg::TWR && TW_FUSE)) {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
             }
-            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, t);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, tl);
             u = un;
             if (a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * b + 8 + iter] = wall_clock64();
             ++iter;
