@@ -52,7 +52,8 @@ import collections
 cnt = collections.Counter(zip(xcc, se, sh, cu))
 print("workgroups per physical CU: " + str(sorted(collections.Counter(cnt.values()).items())))
 its = (tr[:, 8:32].astype(np.int64) - tr[:, 0:1].astype(np.int64)) / 100.0
-valid = tr[:, 8:32] != 0
+# the trace buffer is not cleared between launches: keep only stamps inside this launch's window
+valid = (tr[:, 8:32] >= tr[:, 0:1]) & (tr[:, 8:32] <= tr[:, 1:2])
 prev = np.concatenate([np.zeros((grid, 1)), its[:, :-1]], axis=1)
 per = np.where(valid, its - prev, np.nan)
 print("mean time of iteration k (us): " + " ".join("%.2f" % x for x in np.nanmean(per, axis=0)[:min(24, int(valid.sum(axis=1).max()))]))
