@@ -541,3 +541,67 @@ def test_batches_beyond_4_gib(n):
     d_in.free()
     d_out.free()
     plan.close()
+
+
+def test_pixel_modes_at_full_size():
+    """BASELINE batch (8192 points x 4096 frames) through the u8 dB epilogues: sampled rows against the
+    oracle (exact on >= 99.9 % of pixels, +-1 elsewhere) and the DC-fix column of the broad mode."""
+    n, nf = 8192, 4096
+    iq = synth_iq(3, 2 * nf * n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_out = DeviceBuffer(nf * n)
+    rows = np.unique(np.r_[0, nf - 1, np.random.default_rng(11).integers(0, nf, 14)])
+    for mode in (fsea.MODE_DB10_U8, fsea.MODE_DB5_U8_DCFIX):
+        plan = fsea.Plan(n, mode=mode)
+        plan.exec_device(d_in.ptr, nf, d_out.ptr)
+        plan.synchronize()
+        px = d_out.download(np.uint8, (nf, n))
+        for f in rows:
+            parity.check_u8(px[f], O.rows(iq[2 * f * n: 2 * (f + 1) * n], 1, n, mode=parity.ORACLE_MODE[mode])[0])
+        if mode == fsea.MODE_DB5_U8_DCFIX:
+            assert np.array_equal(px[:, n // 2], px[:, n // 2 - 1])        # c/fft-batch-broad.c:113-115
+        plan.close()
+    d_in.free()
+    d_out.free()
+
+
+def test_linearity_and_bitwise_reproducibility_at_full_size():
+    """Two size-independent properties on the BASELINE batch: the transform is linear
+    (X[a + b] = X[a] + X[b] up to fp32 rounding; the offset-binary DC sits in bin N/2 once per
+    transform), and a launch is deterministic down to the bit although frames are handed out
+    dynamically (tickets, stealing), also across different launch geometries (a sub-batch)."""
+    n, nf = 8192, 4096
+    rng = np.random.default_rng(21)
+    a = np.clip(np.rint(rng.normal(0, 14, 2 * nf * n)), -60, 60).astype(np.int8)
+    b = np.clip(np.rint(rng.normal(0, 14, 2 * nf * n)), -60, 60).astype(np.int8)
+    c = (a + b).astype(np.int8)                                          # |a + b| <= 120: no wrap
+    plan = fsea.Plan(n, mode=fsea.MODE_COMPLEX_F32)
+    d_in = DeviceBuffer(a.nbytes)
+    d_out = DeviceBuffer(nf * n * 8)
+    spectra = []
+    for x in (a, b, c):
+        d_in.upload(x.view(np.uint8))
+        plan.exec_device(d_in.ptr, nf, d_out.ptr)
+        plan.synchronize()
+        spectra.append(d_out.download(np.complex64, (nf, n)))
+    xa, xb, xc = spectra
+    dc = 0.5 * n * (1 + 1j)                                              # every u8 transform carries it once
+    rows = np.unique(np.r_[0, nf - 1, rng.integers(0, nf, 62)])
+    want = xa[rows].astype(np.complex128) + xb[rows].astype(np.complex128)
+    want[:, n // 2] -= dc
+    got = xc[rows].astype(np.complex128)
+    err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() < 1e-6, err.max()
+    # the same launch again, and the second half alone: identical bits
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    again = d_out.download(np.complex64, (nf, n))
+    assert np.array_equal(again.view(np.uint32), xc.view(np.uint32))
+    half = nf // 2
+    plan.exec_device(d_in.ptr.value + 2 * half * n, nf - half, d_out.ptr)
+    plan.synchronize()
+    tail = d_out.download(np.complex64, (nf, n))[: nf - half]
+    assert np.array_equal(tail.view(np.uint32), xc[half:].view(np.uint32))
+    d_in.free()
+    d_out.free()
+    plan.close()
