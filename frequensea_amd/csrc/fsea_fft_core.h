@@ -198,7 +198,9 @@ struct FftCfg {
     // 16 = a middle pass that reads 16 bytes per lane (C = 2, P = 32) rotates its lanes inside every
     //     16-lane block by the block index: the pad shifts each block by one 16-byte slot, which
     //     puts two lanes of every ds_read_b128 lane group on one slot (8 instead of 4 LDS cycles
-    //     per instruction; scripts/lds_conflicts.py); rotated, the groups are conflict-free.
+    //     per instruction; scripts/lds_conflicts.py); rotated, the groups are conflict-free;
+    // 32 = the same renumbering for the last pass (and the cross-block form for 8-byte layouts, see
+    //     pass_lane); measured null, off everywhere.
     static constexpr int OPT = OPT_;
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
