@@ -96,3 +96,22 @@ def test_narrow_sweep_overlapping_stitch(tmp_path):
     outside[markers_y:markers_y + 48] = False
     assert np.array_equal(img[rows:][outside[rows:]], axis[rows:][outside[rows:]])
     assert labels[0][1] == "1800.00" and img[markers_y:markers_y + 48, labels[0][0]:].any()
+
+
+def test_gpu_stitch_equals_the_reference_binary(tmp_path):
+    """fsea-fft-stitch --broad (max-composite on the GPU) against the reference's own
+    c/fft-stitch-broad.c compiled as is (oracle/_ref/fft-stitch-broad): same tiles in, same image out."""
+    from tests.test_reference_tools import REF_STITCH_BROAD, _png_io, _read, run_reference_stitch_broad
+    if not os.path.exists(REF_STITCH_BROAD):
+        pytest.skip("oracle/_ref/fft-stitch-broad not built")
+    L = _png_io()
+    rng = np.random.default_rng(5)
+    for f in (900, 905, 910, 915):
+        t = rng.integers(0, 256, (4096, 256), dtype=np.uint8)
+        assert L.write_gray_png(str(tmp_path / ("broad-%d.png" % f)).encode(), 256, 4096, t.ctypes.data) == 0
+    ref = _read(L, run_reference_stitch_broad(tmp_path, 900, 915))
+    os.rename(tmp_path / "broad-stitched-900-915.png", tmp_path / "reference.png")
+    subprocess.run([os.path.join(BIN, "fsea-fft-stitch"), "--broad", "--start", "900", "--end", "915", "--rows", "4096",
+                    "--dir", str(tmp_path)], capture_output=True, text=True, check=True)
+    ours = _read(L, tmp_path / "broad-stitched-900-915.png")
+    assert ours.shape == ref.shape == (4096, 1024) and np.array_equal(ours, ref)
