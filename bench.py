@@ -16,9 +16,11 @@ Extra objects on that line:
   roofline      dominant kernel vs the HBM roofline: algorithmic bytes per launch
                 (2*hop + 4*N per frame) / average launch duration measured with HIP events on
                 the launch stream over the timed region.
-  cpu_baseline  the oracle's reference-shaped CPU loop (oracle/fsea_oracle.c, kind "port";
-                FFTW is not installed in this image) timed on this host's cores on a bounded
-                sample of the same workload.  A reported baseline, not the target.
+  cpu_baseline  the reference-shaped CPU loop (oracle/fsea_oracle.c, kind "port") timed on this
+                host's cores on a bounded sample of the same workload; the transform inside it is
+                an FFTW3-API library's when the host has one (libfftw3 is not installed in this
+                image, Intel MKL's FFTW3 interface is), else the oracle's own.  A reported
+                baseline, not the target.
   extra         the same measurement at N=1024 (the other size BASELINE.json's metric names).
 
 PyTorch is plumbing only here: device buffers, streams, torch.distributed.
@@ -229,27 +231,69 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
     return line
 
 
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs under a quota of 16; more threads than that only get throttled)."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    note = ""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = text[0], float(text[1])
+            else:
+                quota, period = text[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period))
+                if q < cpus:
+                    note = "cgroup CPU quota %d of %d visible CPUs" % (q, cpus)
+                    cpus = q
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cpus, note
+
+
 def cpu_baseline(n, hop, cores, budget_s):
-    """Oracle port timed on this host (bounded sample: about `budget_s` core-seconds)."""
+    """The reference-shaped CPU loop (flip -> unpack/centre -> FFT -> magnitude, oracle/fsea_oracle.c)
+    timed on this host, bounded sample of about `budget_s` core-seconds.  The transform is done by an
+    FFTW3-API library when the host has one -- the reference's own calls, fftw_plan_dft_1d +
+    fftw_execute, one plan per thread -- i.e. FFTW itself, or Intel MKL through its FFTW3 interface;
+    otherwise by the oracle's radix-2 f64 FFT.  kind "port" either way: the loop is this repo's."""
     from oracle import oracle as O
 
-    probe_frames = 32
-    buf_frames = 2048                                        # 32 MiB at N=8192; reused cyclically
+    fftw = O.find_fftw_api()
+    buf_frames = max(2048, 16 * cores)                       # >= 16 frames per thread and pass
     iq = synth_batch(3, 2 * ((buf_frames - 1) * hop + n))
-    t = O.time_mag_rows(iq, probe_frames, n, hop)            # 1 thread calibration
-    per_frame = max(t / probe_frames, 1e-7)
+    if fftw is None:
+        def run(frames_, threads, passes=1):
+            return sum(O.time_mag_rows(iq, frames_, n, hop, threads=threads) for _ in range(passes))
+        fft_name = "oracle/fsea_oracle.c radix-2 f64 FFT (no FFTW3-API library on this host)"
+    else:
+        def run(frames_, threads, passes=1):                 # threads and plans are made once per call
+            return O.time_mag_rows_fftw(fftw, iq, frames_, n, hop, threads=threads, passes=passes)[0]
+        fft_name = ("FFT by %s through the FFTW3 API (fftw_plan_dft_1d FFTW_MEASURE + fftw_execute, as src/nrf.c:562-615)"
+                    % ("Intel MKL (%s)" % fftw if "mkl" in fftw else fftw))
+    probe_frames = 64
+    run(probe_frames, 1)                                     # library load, planner
+    per_frame = max(run(probe_frames, 1) / probe_frames, 1e-7)
+    f1 = min(buf_frames, max(64, int(2.0 / per_frame)))
+    one_thread = f1 / run(f1, 1)
     reps = int(max(1, round(budget_s / per_frame / buf_frames)))
     frames = reps * buf_frames
-    t1 = O.time_mag_rows(iq, min(buf_frames, max(64, int(2.0 / per_frame))), n, hop)
-    one_thread = min(buf_frames, max(64, int(2.0 / per_frame))) / t1
-    tm = 0.0
-    for _ in range(reps):
-        tm += O.time_mag_rows(iq, buf_frames, n, hop, threads=cores)
-    return dict(value=frames / tm, unit="frames/s", cores=cores, kind="port",
-                sample="%d frames (%d passes over a %d-frame synthetic N=%d batch; oracle/fsea_oracle.c radix-2 "
-                       "f64 FFT, frames sharded over %d threads, one plan per thread; FFTW not installed)"
-                       % (frames, reps, buf_frames, n, cores),
-                one_thread=one_thread)
+    run(min(buf_frames, 16 * cores), cores)                  # warm the cores
+    tm = run(buf_frames, cores, reps)
+    out = dict(value=frames / tm, unit="frames/s", cores=cores, kind="port",
+               sample="%d frames (%d passes over a %d-frame synthetic N=%d batch, frames sharded over %d threads, "
+                      "one plan per thread); %s" % (frames, reps, buf_frames, n, cores, fft_name),
+               one_thread=one_thread)
+    if fftw is not None:                                     # the oracle's own FFT beside it, short sample
+        t = O.time_mag_rows(iq, buf_frames, n, hop, threads=cores)
+        out["oracle_fft_value"] = buf_frames / t
+    return out
 
 
 def main():
@@ -358,8 +402,10 @@ def main():
                          "kernel_n1024": ex["kernel"], "avg_launch_ms_n1024": ex["kernel_ms"]}
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        cores, quota_note = effective_cpus()
         cb = cpu_baseline(n, hop, cores, args.cpu_budget)
+        if quota_note:
+            cb["sample"] += "; " + quota_note
         line["cpu_baseline"] = cb
         line["gpu_over_cpu_all_cores"] = value / cb["value"]
 

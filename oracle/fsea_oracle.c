@@ -411,22 +411,29 @@ typedef struct {
     int n;
     size_t hop;
     double checksum;
+    pthread_barrier_t *gate; /* crossed twice: plans ready -> timed region starts; work done */
 } orc_mt_job;
 
 static void *orc_mt_worker(void *arg) {
     orc_mt_job *job = (orc_mt_job *)arg;
     orc_plan p;
-    if (orc_plan_init(&p, job->n) != 0) return NULL;
+    if (orc_plan_init(&p, job->n) != 0) {
+        pthread_barrier_wait(job->gate);
+        pthread_barrier_wait(job->gate);
+        return NULL;
+    }
     const int n = job->n;
     uint8_t *tmp_u8 = (uint8_t *)malloc((size_t)2 * (size_t)n);
     double *tmp_in = (double *)malloc(sizeof(double) * 2 * (size_t)n);
     double *tmp_out = (double *)malloc(sizeof(double) * 2 * (size_t)n);
     double *row = (double *)malloc(sizeof(double) * (size_t)n);
     double acc = 0;
+    pthread_barrier_wait(job->gate);
     for (size_t f = job->f0; f < job->f1; f++) {
         orc_one_row(&p, job->iq + 2 * f * job->hop, 1, 0, tmp_u8, tmp_in, tmp_out, row);
         acc += row[1];
     }
+    pthread_barrier_wait(job->gate);
     job->checksum = acc;
     free(tmp_u8);
     free(tmp_in);
@@ -443,23 +450,154 @@ double orc_time_mag_rows_mt(const uint8_t *iq, size_t n_frames, int n, size_t ho
     if (n_threads < 1) n_threads = 1;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
     orc_mt_job *jobs = (orc_mt_job *)calloc((size_t)n_threads, sizeof(orc_mt_job));
-    double t0 = now_seconds();
+    pthread_barrier_t gate;
+    pthread_barrier_init(&gate, NULL, (unsigned)n_threads + 1u);
     for (int t = 0; t < n_threads; t++) {
         jobs[t].iq = iq;
         jobs[t].n = n;
         jobs[t].hop = hop;
         jobs[t].f0 = n_frames * (size_t)t / (size_t)n_threads;
         jobs[t].f1 = n_frames * (size_t)(t + 1) / (size_t)n_threads;
+        jobs[t].gate = &gate;
         pthread_create(&th[t], NULL, orc_mt_worker, &jobs[t]);
     }
+    /* planning (FFTW_MEASURE in the reference, src/nrf.c:564) is a one-off cost and stays outside */
+    pthread_barrier_wait(&gate);
+    double t0 = now_seconds();
+    pthread_barrier_wait(&gate);
+    double t1 = now_seconds();
     double acc = 0;
     for (int t = 0; t < n_threads; t++) {
         pthread_join(th[t], NULL);
         acc += jobs[t].checksum;
     }
-    double t1 = now_seconds();
+    pthread_barrier_destroy(&gate);
     if (checksum) *checksum = acc;
     free(th);
     free(jobs);
     return t1 - t0;
+}
+
+/* ---- cpu_baseline through an FFTW3-API library (dlopen) ------------------- */
+
+#include <dlfcn.h>
+
+typedef void *(*fftw_plan_dft_1d_fn)(int, double *, double *, int, unsigned);
+typedef void (*fftw_execute_fn)(void *);
+typedef void (*fftw_destroy_plan_fn)(void *);
+
+typedef struct {
+    const uint8_t *iq;
+    size_t f0, f1;
+    int n;
+    size_t hop;
+    double checksum;
+    double *rows;
+    size_t rows_cap;
+    int passes;
+    fftw_plan_dft_1d_fn plan_fn;
+    fftw_execute_fn exec_fn;
+    fftw_destroy_plan_fn destroy_fn;
+    pthread_mutex_t *planner;
+    pthread_barrier_t *gate;
+    int failed;
+} orc_fftw_job;
+
+static void *orc_fftw_worker(void *arg) {
+    orc_fftw_job *job = (orc_fftw_job *)arg;
+    const int n = job->n;
+    uint8_t *tmp_u8 = (uint8_t *)malloc((size_t)2 * (size_t)n);
+    double *in = NULL, *out = NULL;
+    double *row = (double *)malloc(sizeof(double) * (size_t)n);
+    void *plan = NULL;
+    if (posix_memalign((void **)&in, 64, sizeof(double) * 2 * (size_t)n) == 0 &&
+        posix_memalign((void **)&out, 64, sizeof(double) * 2 * (size_t)n) == 0) {
+        pthread_mutex_lock(job->planner); /* FFTW's planner is not thread-safe */
+        plan = job->plan_fn(n, in, out, -1 /* FFTW_FORWARD */, 0u /* FFTW_MEASURE */);
+        pthread_mutex_unlock(job->planner);
+    }
+    if (plan == NULL) {
+        job->failed = 1;
+        pthread_barrier_wait(job->gate);
+        pthread_barrier_wait(job->gate);
+        return NULL;
+    }
+    double acc = 0;
+    pthread_barrier_wait(job->gate);
+    for (int pass = 0; pass < job->passes; pass++) {
+        for (size_t f = job->f0; f < job->f1; f++) {
+            orc_flip_u8(job->iq + 2 * f * job->hop, tmp_u8, (size_t)2 * (size_t)n); /* a1 */
+            orc_unpack_center_u8(tmp_u8, (size_t)n, in);                             /* a4 */
+            job->exec_fn(plan);                                                      /* a5 */
+            orc_mag_row(out, n, row);                                                /* a7 */
+            acc += row[1];
+            if (job->rows != NULL && f < job->rows_cap) {
+                memcpy(job->rows + f * (size_t)n, row, sizeof(double) * (size_t)n);
+            }
+        }
+    }
+    pthread_barrier_wait(job->gate);
+    job->checksum = acc;
+    pthread_mutex_lock(job->planner);
+    job->destroy_fn(plan);
+    pthread_mutex_unlock(job->planner);
+    free(tmp_u8);
+    free(in);
+    free(out);
+    free(row);
+    return NULL;
+}
+
+double orc_time_mag_rows_fftw(const char *lib, const uint8_t *iq, size_t n_frames, int n, size_t hop,
+                              int n_threads, int passes, double *rows, size_t rows_cap, double *checksum) {
+    void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (h == NULL) return -1.0;
+    fftw_plan_dft_1d_fn plan_fn;
+    fftw_execute_fn exec_fn;
+    fftw_destroy_plan_fn destroy_fn;
+    /* the POSIX idiom for dlsym -> function pointer under -pedantic */
+    *(void **)(&plan_fn) = dlsym(h, "fftw_plan_dft_1d");
+    *(void **)(&exec_fn) = dlsym(h, "fftw_execute");
+    *(void **)(&destroy_fn) = dlsym(h, "fftw_destroy_plan");
+    if (plan_fn == NULL || exec_fn == NULL || destroy_fn == NULL) return -2.0;
+    if (n_threads < 1) n_threads = 1;
+    pthread_mutex_t planner;
+    pthread_mutex_init(&planner, NULL);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    orc_fftw_job *jobs = (orc_fftw_job *)calloc((size_t)n_threads, sizeof(orc_fftw_job));
+    pthread_barrier_t gate;
+    pthread_barrier_init(&gate, NULL, (unsigned)n_threads + 1u);
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].iq = iq;
+        jobs[t].n = n;
+        jobs[t].hop = hop;
+        jobs[t].f0 = n_frames * (size_t)t / (size_t)n_threads;
+        jobs[t].f1 = n_frames * (size_t)(t + 1) / (size_t)n_threads;
+        jobs[t].rows = rows;
+        jobs[t].rows_cap = rows_cap;
+        jobs[t].passes = passes < 1 ? 1 : passes;
+        jobs[t].plan_fn = plan_fn;
+        jobs[t].exec_fn = exec_fn;
+        jobs[t].destroy_fn = destroy_fn;
+        jobs[t].planner = &planner;
+        jobs[t].gate = &gate;
+        pthread_create(&th[t], NULL, orc_fftw_worker, &jobs[t]);
+    }
+    pthread_barrier_wait(&gate); /* every thread has its plan: planning stays outside the timed region */
+    double t0 = now_seconds();
+    pthread_barrier_wait(&gate);
+    double t1 = now_seconds();
+    double acc = 0;
+    int failed = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        acc += jobs[t].checksum;
+        failed |= jobs[t].failed;
+    }
+    pthread_barrier_destroy(&gate);
+    if (checksum) *checksum = acc;
+    free(th);
+    free(jobs);
+    pthread_mutex_destroy(&planner);
+    return failed ? -3.0 : t1 - t0;
 }

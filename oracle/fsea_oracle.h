@@ -116,9 +116,22 @@ double orc_time_mag_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop,
                          double *sink);
 
 /* Same loop with frames sharded over n_threads pthreads, one plan per thread
- * (BASELINE.md section 4 item 2(ii)).  Returns wall seconds. */
+ * (BASELINE.md section 4 item 2(ii)).  Returns wall seconds of the transform loop (thread start-up
+ * and planning excluded). */
 double orc_time_mag_rows_mt(const uint8_t *iq, size_t n_frames, int n, size_t hop,
                             int n_threads, double *checksum);
+
+/* The same reference-shaped loop with the transform done by an FFTW3-API library loaded at run
+ * time -- exactly the calls the reference makes (src/nrf.c:562-564,615: fftw_plan_dft_1d(n, in, out,
+ * FFTW_FORWARD, FFTW_MEASURE), fftw_execute), one plan per thread, planner calls serialised.
+ * `lib`: path or soname, e.g. "libfftw3.so.3", or Intel MKL's "libmkl_rt.so", which exports the
+ * FFTW3 interface.  If rows != NULL the first min(n_frames, rows_cap) magnitude rows are stored
+ * there (rows_cap * n doubles) so that the library can be checked against the oracle's own FFT.
+ * Every thread walks its share of the frames `passes` times; threads and plans are made once,
+ * before the timed region (planning is a one-off cost in the reference too, src/nrf.c:564).
+ * Returns wall seconds, or a negative value when the library or a symbol cannot be loaded. */
+double orc_time_mag_rows_fftw(const char *lib, const uint8_t *iq, size_t n_frames, int n, size_t hop,
+                              int n_threads, int passes, double *rows, size_t rows_cap, double *checksum);
 
 #ifdef __cplusplus
 }

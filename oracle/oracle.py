@@ -70,8 +70,43 @@ def lib():
         L.orc_time_mag_rows_mt.argtypes = [c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t,
                                            ctypes.c_int, c_f64p]
         L.orc_time_mag_rows_mt.restype = ctypes.c_double
+        L.orc_time_mag_rows_fftw.argtypes = [ctypes.c_char_p, c_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t,
+                                             ctypes.c_int, ctypes.c_int, c_f64p, ctypes.c_size_t, c_f64p]
+        L.orc_time_mag_rows_fftw.restype = ctypes.c_double
         _LIB = L
     return _LIB
+
+
+# FFTW3-API libraries to try for the CPU baseline, in order: FFTW itself, then Intel MKL, whose
+# libmkl_rt exports the FFTW3 interface (fftw_plan_dft_1d / fftw_execute) on top of its own DFT.
+FFTW_CANDIDATES = ["libfftw3.so.3", "libfftw3.so", "/opt/conda/lib/libmkl_rt.so", "libmkl_rt.so", "libmkl_rt.so.1"]
+
+
+def find_fftw_api():
+    """First loadable FFTW3-API library (path/soname) or None."""
+    os.environ.setdefault("MKL_NUM_THREADS", "1")      # one plan per thread, no nested threading
+    for cand in FFTW_CANDIDATES:
+        try:
+            h = ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            continue
+        if hasattr(h, "fftw_plan_dft_1d") and hasattr(h, "fftw_execute"):
+            return cand
+    return None
+
+
+def time_mag_rows_fftw(lib_name, iq, n_frames, n, hop=None, threads=1, keep_rows=0, passes=1):
+    """Reference-shaped loop with an FFTW3-API library doing the transform: (seconds for `passes`
+    walks over the frames, rows or None)."""
+    hop = n if hop is None else hop
+    iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
+    rows_ = np.zeros((keep_rows, n), np.float64) if keep_rows else None
+    chk = ctypes.c_double(0)
+    t = lib().orc_time_mag_rows_fftw(lib_name.encode(), _u8p(iq), n_frames, n, hop, threads, passes,
+                                     _f64p(rows_) if keep_rows else None, keep_rows, ctypes.byref(chk))
+    if t < 0:
+        raise RuntimeError("orc_time_mag_rows_fftw(%s) failed: %g" % (lib_name, t))
+    return t, rows_
 
 
 def _u8p(a):

@@ -228,3 +228,21 @@ def test_rows_shifted_by_whole_bins_rotates_the_spectrum():
     # a constant phase only rotates the shifted part
     ph = O.rows_shifted(raw, nf, n, 0.0, 0.25, mode=O.MODE_COMPLEX)
     assert np.abs(ph - (1j * plain + dc)).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------
+# a5 against an FFTW3-API library, when the image has one (FFTW itself, or Intel MKL's libmkl_rt,
+# which implements fftw_plan_dft_1d / fftw_execute): the calls the reference makes, src/nrf.c:562-615
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [128, 1024, 8192, 16384])
+def test_oracle_fft_against_an_fftw3_api_library(golden, n):
+    lib_name = O.find_fftw_api()
+    if lib_name is None:
+        pytest.skip("no FFTW3-API library in this image")
+    raw = np.concatenate([golden["rf_100p900_1__flipped"], golden["rf_202p500_2__flipped"]]) ^ np.uint8(0x80)
+    nf = raw.size // (2 * n)
+    _, got = O.time_mag_rows_fftw(lib_name, raw, nf, n, threads=3, keep_rows=nf)
+    want = O.rows(raw, nf, n)
+    assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+    if n in GOLDEN_SIZES:
+        assert np.abs(got[0] - golden["rf_100p900_1__mag_%d" % n]).max() <= 1e-9 * np.abs(want).max()
