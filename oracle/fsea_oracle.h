@@ -20,8 +20,15 @@
  *     (tests/golden/make_golden.py, committed fixtures);
  *   - the known-answer values SURVEY.md section 8(c) recorded from the
  *     reference's own nrf.c;
+ *   - an FFTW3-API library driven through the reference's own calls
+ *     (fftw_plan_dft_1d + fftw_execute; Intel MKL's interface in this image,
+ *     orc_time_mag_rows_fftw + tests/test_oracle.py) -- an independent
+ *     implementation, not FFTW itself;
  *   - oracle/_ref/libnut_ref.so = the reference's src/nut.c compiled as is
- *     (it needs no third-party headers) pins the nut_buffer conventions.
+ *     (it needs no third-party headers) pins the nut_buffer conventions;
+ *   - oracle/_ref/fft-stitch-broad = the reference's c/fft-stitch-broad.c
+ *     compiled as is against the image's libpng pins orc_composite_max and
+ *     the PNG tile format (tests/test_reference_tools.py).
  *
  * Every function cites the reference lines it follows (paths relative to
  * /root/reference).
