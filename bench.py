@@ -354,7 +354,7 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     if args.workload == "broad":
-        line = run_broad(args, rank, world, dist, torch, max(1, args.steps // 20), max(1, args.warmup // 10))
+        line = run_broad(args, rank, world, dist, torch, max(1, args.steps), max(1, args.warmup))
         if rank == 0:
             print(json.dumps(line))
         if dist is not None:
