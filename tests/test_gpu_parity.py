@@ -605,3 +605,27 @@ def test_linearity_and_bitwise_reproducibility_at_full_size():
     d_in.free()
     d_out.free()
     plan.close()
+
+
+@pytest.mark.parametrize("n,nf,mode", [(128, 33, 1), (1024, 9, 0), (2048, 5, 3), (4096, 3, 2), (8192, 13, 0),
+                                       (8192, 1, 5), (16384, 2, 1)])
+def test_no_write_outside_the_output_rows(n, nf, mode):
+    """Ragged launches (frame counts that do not fill the last unit, fewer frames than workgroups)
+    must not touch a byte before or after their n_frames rows: guard bands around the output."""
+    guard = 1 << 16
+    plan = fsea.Plan(n, mode=mode)
+    out_bytes = nf * plan.row_bytes
+    iq = synth_iq(77 + n + nf, 2 * nf * n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    pattern = np.full(guard + out_bytes + guard, 0xA5, np.uint8)
+    d_buf = DeviceBuffer(pattern.nbytes).upload(pattern)
+    plan.exec_device(d_in.ptr, nf, ctypes.c_void_p(d_buf.ptr.value + guard))
+    plan.synchronize()
+    back = d_buf.download(np.uint8, (pattern.nbytes,))
+    assert np.all(back[:guard] == 0xA5) and np.all(back[guard + out_bytes:] == 0xA5)
+    got = back[guard: guard + out_bytes].view(plan.out_dtype).reshape(nf, n)
+    parity.check_mode(got, iq, n, nf, n, True, mode)
+    # the input is not padded either: the last frame ends at the last byte of the buffer
+    d_in.free()
+    d_buf.free()
+    plan.close()
