@@ -167,7 +167,9 @@ int fsea_time_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
  * launch (scripts/wg_trace.py). */
 int fsea_plan_read_trace(fsea_plan *plan, unsigned long long *out, unsigned n_workgroups);
 
-/* Name of the kernel variant the plan launches (for matching rocprof rows). */
+/* Name of the kernel the plan launches (for matching rocprof rows).  MAG_F32 plans name the
+ * compile-time kernel `*_u8_mag`, which serves flip != 0 (raw int8 input); with flip == 0 the same
+ * plan launches the run-time-mode kernel `*_u8`. */
 const char *fsea_plan_kernel_name(const fsea_plan *plan);
 
 const char *fsea_last_error_string(void);
