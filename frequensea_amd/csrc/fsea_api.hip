@@ -203,6 +203,12 @@ struct fsea_plan {
     void *d_aux = nullptr;
     size_t d_aux_bytes = 0;
     double *d_acc = nullptr;
+    // small host batches (the nrf_fft_process pattern: one 2 KiB frame in, one row out) go through
+    // pinned, device-mapped staging: the kernel reads and writes host memory itself, so a call is
+    // one launch and one synchronisation instead of copy + launch + copy
+    void *h_in = nullptr;
+    void *h_out = nullptr;
+    size_t h_in_bytes = 0, h_out_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string kernel_name;
 };
@@ -218,6 +224,21 @@ int ensure(void **ptr, size_t *cap, size_t need) {
     }
     size_t want = need + need / 4 + 4096;
     FSEA_HIP(hipMalloc(ptr, want));
+    *cap = want;
+    return FSEA_OK;
+}
+
+constexpr size_t FSEA_ZERO_COPY_MAX = 256 * 1024;  // in + out bytes up to which the staging is mapped host memory
+
+int ensure_pinned(void **ptr, size_t *cap, size_t need) {
+    if (*cap >= need) return FSEA_OK;
+    if (*ptr) {
+        FSEA_HIP(hipHostFree(*ptr));
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    const size_t want = need < 65536 ? 65536 : need;
+    FSEA_HIP(hipHostMalloc(ptr, want, hipHostMallocMapped));
     *cap = want;
     return FSEA_OK;
 }
@@ -358,6 +379,8 @@ int fsea_plan_destroy(fsea_plan *p) {
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->d_aux) (void)hipFree(p->d_aux);
     if (p->d_acc) (void)hipFree(p->d_acc);
+    if (p->h_in) (void)hipHostFree(p->h_in);
+    if (p->h_out) (void)hipHostFree(p->h_out);
     if (p->d_trace) (void)hipFree(p->d_trace);
     if (p->d_ctr) (void)hipFree(p->d_ctr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -395,7 +418,11 @@ int fsea_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int fli
                   static_cast<hipStream_t>(stream));
 }
 
-int fsea_exec_u8_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip, void *out) {
+namespace {
+
+// Common body of the u8 host entry points.
+int exec_u8_host(fsea_plan *p, int in_kind, const uint8_t *iq, size_t n_frames, int flip, void *out, double rot_delta,
+                 double rot_phase0) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
     if (n_frames == 0) return FSEA_OK;
     if (!iq || !out) return fail(FSEA_EINVAL, "NULL buffer");
@@ -403,16 +430,37 @@ int fsea_exec_u8_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip
     FSEA_HIP(hipSetDevice(p->device));
     const size_t in_bytes = 2 * ((n_frames - 1) * (size_t)p->hop + (size_t)p->n);
     const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
+    if (in_bytes + out_bytes <= FSEA_ZERO_COPY_MAX) {
+        int rc = ensure_pinned(&p->h_in, &p->h_in_bytes, in_bytes);
+        if (rc) return rc;
+        rc = ensure_pinned(&p->h_out, &p->h_out_bytes, out_bytes);
+        if (rc) return rc;
+        void *d_in = nullptr, *d_out = nullptr;
+        FSEA_HIP(hipHostGetDevicePointer(&d_in, p->h_in, 0));
+        FSEA_HIP(hipHostGetDevicePointer(&d_out, p->h_out, 0));
+        std::memcpy(p->h_in, iq, in_bytes);
+        rc = launch(p, in_kind, d_in, n_frames, flip, p->mode, d_out, p->stream, rot_delta, rot_phase0);
+        if (rc) return rc;
+        FSEA_HIP(hipStreamSynchronize(p->stream));
+        std::memcpy(out, p->h_out, out_bytes);
+        return FSEA_OK;
+    }
     int rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes);
     if (rc) return rc;
     rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
     if (rc) return rc;
     FSEA_HIP(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
-    rc = launch(p, fsea::IN_U8, p->d_in, n_frames, flip, p->mode, p->d_out, p->stream);
+    rc = launch(p, in_kind, p->d_in, n_frames, flip, p->mode, p->d_out, p->stream, rot_delta, rot_phase0);
     if (rc) return rc;
     FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
     FSEA_HIP(hipStreamSynchronize(p->stream));
     return FSEA_OK;
+}
+
+}  // namespace
+
+int fsea_exec_u8_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip, void *out) {
+    return exec_u8_host(p, fsea::IN_U8, iq, n_frames, flip, out, 0.0, 0.0);
 }
 
 int fsea_exec_u8_shifted_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, double cycles_per_sample,
@@ -429,27 +477,10 @@ int fsea_exec_u8_shifted_device(fsea_plan *p, const void *d_iq, size_t n_frames,
 
 int fsea_exec_u8_shifted_host(fsea_plan *p, const uint8_t *iq, size_t n_frames, int flip, double cycles_per_sample,
                               double phase0_cycles, void *out) {
-    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
-    if (n_frames == 0) return FSEA_OK;
-    if (!iq || !out) return fail(FSEA_EINVAL, "NULL buffer");
     if (!std::isfinite(cycles_per_sample) || !std::isfinite(phase0_cycles)) {
         return fail(FSEA_EINVAL, "frequency shift must be finite");
     }
-    std::lock_guard<std::mutex> lock(p->mu);
-    FSEA_HIP(hipSetDevice(p->device));
-    const size_t in_bytes = 2 * ((n_frames - 1) * (size_t)p->hop + (size_t)p->n);
-    const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
-    int rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes);
-    if (rc) return rc;
-    rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
-    if (rc) return rc;
-    FSEA_HIP(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
-    rc = launch(p, fsea::IN_U8_ROT, p->d_in, n_frames, flip, p->mode, p->d_out, p->stream, cycles_per_sample,
-                phase0_cycles);
-    if (rc) return rc;
-    FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-    FSEA_HIP(hipStreamSynchronize(p->stream));
-    return FSEA_OK;
+    return exec_u8_host(p, fsea::IN_U8_ROT, iq, n_frames, flip, out, cycles_per_sample, phase0_cycles);
 }
 
 int fsea_exec_f64_host(fsea_plan *p, const double *iq, size_t n_frames, void *out) {
