@@ -491,6 +491,24 @@ int fsea_exec_f64_host(fsea_plan *p, const double *iq, size_t n_frames, void *ou
     FSEA_HIP(hipSetDevice(p->device));
     const size_t n_samples = (n_frames - 1) * (size_t)p->hop + (size_t)p->n;
     const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
+    if (n_samples * 2 * sizeof(float) + out_bytes <= FSEA_ZERO_COPY_MAX) {
+        // small batch (nrf_fft_process on a shifter buffer): narrow to f32 on the host, straight into
+        // the mapped staging; one launch, one synchronisation
+        int rc0 = ensure_pinned(&p->h_in, &p->h_in_bytes, n_samples * 2 * sizeof(float));
+        if (rc0) return rc0;
+        rc0 = ensure_pinned(&p->h_out, &p->h_out_bytes, out_bytes);
+        if (rc0) return rc0;
+        void *d_in = nullptr, *d_out = nullptr;
+        FSEA_HIP(hipHostGetDevicePointer(&d_in, p->h_in, 0));
+        FSEA_HIP(hipHostGetDevicePointer(&d_out, p->h_out, 0));
+        float *dst = static_cast<float *>(p->h_in);
+        for (size_t i = 0; i < n_samples * 2; ++i) dst[i] = (float)iq[i];
+        rc0 = launch(p, fsea::IN_F32, d_in, n_frames, 0, p->mode, d_out, p->stream);
+        if (rc0) return rc0;
+        FSEA_HIP(hipStreamSynchronize(p->stream));
+        std::memcpy(out, p->h_out, out_bytes);
+        return FSEA_OK;
+    }
     int rc = ensure(&p->d_aux, &p->d_aux_bytes, n_samples * 2 * sizeof(double));
     if (rc) return rc;
     rc = ensure(&p->d_in, &p->d_in_bytes, n_samples * 2 * sizeof(float));
