@@ -227,8 +227,8 @@ def test_concurrent_launches_of_one_plan_on_two_streams():
     plan.close()
 
 
-def test_f64_input_branch():
-    n, nf = 1024, 7
+@pytest.mark.parametrize("n,nf", [(1024, 7), (4096, 40)])      # mapped-staging path / copy path (> 256 KiB)
+def test_f64_input_branch(n, nf):
     rng = np.random.default_rng(3)
     x = rng.normal(0, 0.2, 2 * nf * n)
     plan = fsea.Plan(n)
