@@ -20,6 +20,7 @@
 
 #include "fsea.h"
 #include "nrf.h"
+#include "nut_private.h"
 
 static void fsea_fatal(const char *what, int rc) {
     /* same convention as src/nrf.c:54-78: print and exit */
@@ -120,7 +121,7 @@ void nrf_fft_process(nrf_fft *fft, nut_buffer *buffer) {
 
 nut_buffer *nrf_fft_get_buffer(nrf_fft *fft) {
     const int n = fft->fft_size, h = fft->fft_history_size;
-    nut_buffer *out = nut_buffer_new_f64(n * h, 1, NULL);
+    nut_buffer *out = nut_private_new_f64_unfilled(n * h, 1); /* both memcpys below cover it entirely */
     pthread_mutex_lock(&fft->mutex);
     const int first = h - fft->ring_head; /* rows from the head to the end of storage */
     memcpy(out->data.f64, fft->buffer + (size_t)fft->ring_head * (size_t)n, sizeof(double) * (size_t)first * (size_t)n);

@@ -8,6 +8,7 @@
  */
 #define _POSIX_C_SOURCE 200809L
 #include "nut.h"
+#include "nut_private.h"
 
 #include <assert.h>
 #include <math.h>
@@ -39,9 +40,9 @@ static void set_payload(nut_buffer *b, void *p) {
     }
 }
 
-/* Zero-filled buffer of `length` x `channels` elements; `init` (may be NULL)
- * supplies the initial contents. */
-static nut_buffer *nut_alloc(nut_buffer_type type, int length, int channels, const void *init) {
+/* Buffer of `length` x `channels` elements: a copy of `init`, or zero-filled when init is NULL.
+ * zeroed = 0 skips the zero fill for callers that overwrite every element themselves. */
+static nut_buffer *nut_alloc_mode(nut_buffer_type type, int length, int channels, const void *init, int zeroed) {
     nut_buffer *b = (nut_buffer *)calloc(1, sizeof(nut_buffer));
     if (b == NULL) {
         fprintf(stderr, "nut_buffer: out of memory\n");
@@ -51,7 +52,9 @@ static nut_buffer *nut_alloc(nut_buffer_type type, int length, int channels, con
     b->length = length;
     b->channels = channels;
     b->size_bytes = (int)((size_t)length * (size_t)channels * elem_size(type));
-    void *p = calloc(b->size_bytes > 0 ? (size_t)b->size_bytes : 1, 1);
+    const size_t bytes = b->size_bytes > 0 ? (size_t)b->size_bytes : 1;
+    /* a recycled heap chunk would be memset by calloc only to be overwritten by the copy below */
+    void *p = (init != NULL || !zeroed) ? malloc(bytes) : calloc(bytes, 1);
     if (p == NULL) {
         fprintf(stderr, "nut_buffer: out of memory (%d bytes)\n", b->size_bytes);
         exit(EXIT_FAILURE);
@@ -59,6 +62,15 @@ static nut_buffer *nut_alloc(nut_buffer_type type, int length, int channels, con
     if (init != NULL && b->size_bytes > 0) memcpy(p, init, (size_t)b->size_bytes);
     set_payload(b, p);
     return b;
+}
+
+static nut_buffer *nut_alloc(nut_buffer_type type, int length, int channels, const void *init) {
+    return nut_alloc_mode(type, length, channels, init, 1);
+}
+
+/* Library-internal (nut_private.h): F64 buffer whose contents the caller is about to write in full. */
+nut_buffer *nut_private_new_f64_unfilled(int n_elements, int n_channels) {
+    return nut_alloc_mode(NUT_BUFFER_F64, n_elements, n_channels, NULL, 0);
 }
 
 nut_buffer *nut_buffer_new_u8(int n_elements, int n_channels, const uint8_t *initial) {
