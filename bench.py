@@ -21,7 +21,9 @@ Extra objects on that line:
                 an FFTW3-API library's when the host has one (libfftw3 is not installed in this
                 image, Intel MKL's FFTW3 interface is), else the oracle's own.  A reported
                 baseline, not the target.
-  extra         the same measurement at N=1024 (the other size BASELINE.json's metric names).
+  extra         the same measurement at N=1024 (the other size BASELINE.json names), and short runs of
+                BASELINE.json's other single-GPU configurations (16384-point 50 %-overlap STFT, the
+                fft-batch-broad sweep with stitch).
 
 PyTorch is plumbing only here: device buffers, streams, torch.distributed.
 """
@@ -417,6 +419,14 @@ def main():
                          "msamples_per_sec_n1024": ex["frames"] * args.steps / ex["wall"] * ex["hop"] / 1e6,
                          "roofline_frac_n1024": exb / (ex["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_n1024": ex["kernel"], "avg_launch_ms_n1024": ex["kernel_ms"]}
+        # BASELINE.json's other single-GPU-measurable configurations, shorter runs (informational)
+        st_steps = max(10, min(args.steps, 300))
+        st = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2)
+        stb = (2 * st["hop"] + 4 * st["n"]) * st["frames"]
+        line["extra"].update({"stft16384_hop8192_frames_per_sec": st["frames"] * st_steps / st["wall"],
+                              "stft16384_roofline_frac": stb / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+        br = run_broad(args, rank, world, dist, torch, 20, 3)
+        line["extra"].update({"broad_sweep_1gpu_frames_per_sec": br["value"], "broad_sweep_1gpu_ms": br["ms_per_step"]})
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cores, quota_note = effective_cpus()
