@@ -629,3 +629,89 @@ def test_no_write_outside_the_output_rows(n, nf, mode):
     d_in.free()
     d_buf.free()
     plan.close()
+
+
+def _repeat_upload(chunk, n_chunks):
+    """Device buffer holding `chunk` (host uint8) n_chunks times back to back."""
+    L = fsea.hip_lib()
+    buf = DeviceBuffer(chunk.nbytes * n_chunks)
+    for k in range(n_chunks):
+        fsea._check(L.fsea_copy_to_device(0, ctypes.c_void_p(buf.ptr.value + k * chunk.nbytes), chunk.ctypes.data,
+                                          chunk.nbytes))
+    return buf
+
+
+def _rows_from_device(d_out, frames, n, dtype):
+    L = fsea.hip_lib()
+    item = np.dtype(dtype).itemsize
+    out = np.empty((len(frames), n), dtype)
+    for i, f in enumerate(frames):
+        fsea._check(L.fsea_copy_to_host(0, out[i].ctypes.data, ctypes.c_void_p(d_out.ptr.value + int(f) * n * item), n * item))
+    return out
+
+
+def test_config_c5_stft_16384_at_full_size():
+    """BASELINE config 5 at its full size: 2^28 samples as one stream, 16384-point frames every 8192
+    samples (32767 frames, 2 GiB of f32 rows).  Sampled rows against the oracle, Parseval on them, and
+    the overlap itself: frames f and f + 1 share half their input, which a per-frame phase ramp makes
+    visible in the complex spectrum of a pure tone (checked through the oracle rows instead)."""
+    n, hop = 16384, 8192
+    chunk = synth_iq(5, 1 << 26)                              # 32 Mi samples, repeated 8 times
+    n_chunks = 8
+    total_samples = n_chunks * (chunk.size // 2)
+    nf = (total_samples - n) // hop + 1
+    assert nf == 32767
+    d_in = _repeat_upload(chunk, n_chunks)
+    d_out = DeviceBuffer(nf * n * 4)
+    plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_MAG_NODC_F32)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    per_chunk = (chunk.size // 2) // hop                      # frames per chunk period: 4096
+    frames = sorted({0, 1, nf - 1, nf - 2, per_chunk - 1, per_chunk, 3 * per_chunk - 1, 17000, 29999})
+    got = _rows_from_device(d_out, frames, n, np.float32).astype(np.float64)
+    stream = np.concatenate([chunk, chunk])                   # enough to cut any frame, also across a chunk seam
+    for row, f in zip(got, frames):
+        s0 = (f * hop) % (chunk.size // 2)
+        iq = stream[2 * s0: 2 * (s0 + n)]
+        want = O.rows(iq, 1, n, mode=O.MODE_MAG_NODC)[0]
+        parity.check_float(row, want)
+        u = (iq ^ np.uint8(0x80)).astype(np.float64) / 256.0
+        assert abs(np.sum(row * row) - n * np.sum(u * u)) / (n * np.sum(u * u)) < 2e-6
+    d_in.free()
+    d_out.free()
+    plan.close()
+
+
+def test_config_c4_broad_sweep_at_full_size():
+    """BASELINE config 4 on one GPU at its full size: 512 centre frequencies x 256 frames x 4096 points
+    -> u8 dB tiles (DB5 + DC fix) -> stitched 256 x 2 097 152 image (c/fft-stitch-broad.c geometry).
+    Sampled rows of sampled tiles against the oracle, and the stitch against the tile stack."""
+    n, rows, tiles = 4096, 256, 512
+    chunk = synth_iq(4, 1 << 26)                              # 8192 frames of IQ, repeated 16 times = 1 GiB
+    d_in = _repeat_upload(chunk, 16)
+    d_px = DeviceBuffer(tiles * rows * n)
+    d_img = DeviceBuffer(rows * tiles * n)
+    L = fsea.hip_lib()
+    zero = np.zeros(1 << 24, np.uint8)
+    for off in range(0, rows * tiles * n, zero.nbytes):
+        fsea._check(L.fsea_copy_to_device(0, ctypes.c_void_p(d_img.ptr.value + off), zero.ctypes.data, zero.nbytes))
+    plan = fsea.Plan(n, mode=fsea.MODE_DB5_U8_DCFIX)
+    plan.exec_device(d_in.ptr, tiles * rows, d_px.ptr)        # tile k = frames [k*256, (k+1)*256)
+    fsea.stitch_tiles_device(d_img.ptr, d_px.ptr, tiles, 0, n, n, rows, tiles * n)
+    plan.synchronize()
+    rng = np.random.default_rng(44)
+    per_chunk = (chunk.size // 2) // n                        # 8192 frames per chunk period
+    for k in sorted({0, 1, 255, 256, 511, *rng.integers(0, tiles, 6)}):
+        for y in sorted({0, rows - 1, *rng.integers(0, rows, 3)}):
+            k, y = int(k), int(y)
+            f = k * rows + y
+            tile_row = _rows_from_device(d_px, [f], n, np.uint8)[0]
+            g = f % per_chunk
+            parity.check_u8(tile_row, O.rows(chunk[2 * g * n: 2 * (g + 1) * n], 1, n, mode=O.MODE_DB5_U8_DCFIX)[0])
+            img_row = np.empty(n, np.uint8)
+            fsea._check(L.fsea_copy_to_host(0, img_row.ctypes.data,
+                                            ctypes.c_void_p(d_img.ptr.value + y * tiles * n + k * n), n))
+            assert np.array_equal(img_row, tile_row)          # no overlap at step = width: max with 0
+    for b in (d_in, d_px, d_img):
+        b.free()
+    plan.close()
