@@ -20,7 +20,13 @@
 
 #include "fsea.h"
 #include "nrf.h"
+#ifdef FSEA_NRF_FFT_ONLY
+/* libfsea_nrf_fft.so: only the five nrf_fft_* functions, to be linked next to the application's own
+ * nut.c / nrf.c; then only the public nut.h interface is available. */
+#define nut_private_new_f64_unfilled(n_elements, n_channels) nut_buffer_new_f64((n_elements), (n_channels), NULL)
+#else
 #include "nut_private.h"
+#endif
 
 static void fsea_fatal(const char *what, int rc) {
     /* same convention as src/nrf.c:54-78: print and exit */
