@@ -715,3 +715,33 @@ def test_config_c4_broad_sweep_at_full_size():
     for b in (d_in, d_px, d_img):
         b.free()
     plan.close()
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_extreme_and_degenerate_inputs(n):
+    """Full-scale and degenerate captures at every size: saturated square wave (+127 / -128 on I and Q),
+    all bytes equal, a single impulse, the Nyquist alternation (which (-1)^n centring turns into DC of
+    the shifted spectrum) -- float rows, complex rows and pixels against the oracle."""
+    frames = []
+    frames.append(np.tile(np.array([0x7f, 0x80, 0x80, 0x7f], np.uint8), n // 2))          # full-scale extremes
+    frames.append(np.full(2 * n, 0x80, np.uint8))                                         # constant -128
+    frames.append(np.full(2 * n, 0x7f, np.uint8))                                         # constant +127
+    imp = np.zeros(2 * n, np.uint8)
+    imp[0], imp[1] = 0x7f, 0x80                                                           # impulse at sample 0
+    frames.append(imp)
+    alt = np.zeros(2 * n, np.uint8)
+    alt[0::4], alt[1::4] = 0x7f, 0x7f                                                     # + + 0 0 ... : fs/2 tone
+    alt[2::4], alt[3::4] = 0x81, 0x81
+    frames.append(alt)
+    iq = np.concatenate(frames)
+    nf = len(frames)
+    for mode in (0, 3, 1, 2, 5):
+        plan = fsea.Plan(n, mode=mode)
+        got = plan.exec_host(iq, nf)
+        parity.check_mode(got, iq, n, nf, n, True, mode)
+        plan.close()
+    # offset-binary convention (flip = 0) on the same bytes
+    plan = fsea.Plan(n, mode=fsea.MODE_COMPLEX_F32)
+    got = plan.exec_host(iq, nf, flip=False)
+    parity.check_mode(got, iq, n, nf, n, False, 3)
+    plan.close()
