@@ -330,6 +330,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=16.0, help="core-seconds for the CPU sample")
     args = ap.parse_args()
 
+    # Kernel arguments in device memory instead of host-coherent memory: the first s_load of a launch
+    # otherwise crosses PCIe (about 0.5 us per 54 us launch here).  A HIP runtime knob, read when HIP
+    # initialises, so it has to be set before torch touches the device; libfsea_hip.so sets the same
+    # default for hosts that load it first.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
