@@ -745,3 +745,64 @@ def test_extreme_and_degenerate_inputs(n):
     got = plan.exec_host(iq, nf, flip=False)
     parity.check_mode(got, iq, n, nf, n, False, 3)
     plan.close()
+
+
+def test_host_threads_share_and_split_plans(golden):
+    """SURVEY 8(b) threading: nrf_fft_* may be called from the Lua thread and from a device RX thread.
+    Four host threads drive four nrf_fft objects at once, then all four push rows into ONE object
+    (its mutex serialises them); every row must be the spectrum of the buffer that was pushed."""
+    import threading
+    L = nrf.nrf_lib()
+    n, h = 1024, 64
+    raws = [golden["rf_100p900_1__flipped"], golden["rf_202p500_1__flipped"],
+            golden["rf_202p500_2__flipped"], golden["rf_202p500_3__flipped"]]
+    keys = ["rf_100p900_1", "rf_202p500_1", "rf_202p500_2", "rf_202p500_3"]
+    wants = [golden["%s__mag_%d" % (k, n)] for k in keys]
+    bufs = [_nut_u8(L, r) for r in raws]
+    errors = []
+
+    def own_object(i):
+        try:
+            fft = L.nrf_fft_new(n, h)
+            for _ in range(h):
+                L.nrf_fft_process(fft, bufs[i])
+            out = L.nrf_fft_get_buffer(fft)
+            hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+            L.nut_buffer_free(out)
+            L.nrf_fft_free(fft)
+            for r in (0, h // 2, h - 1):
+                parity.check_float(hist[r], wants[i])
+        except Exception as e:                                  # surfaced in the main thread below
+            errors.append(e)
+
+    threads = [threading.Thread(target=own_object, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+    shared = L.nrf_fft_new(n, h)
+
+    def shared_object(i):
+        for _ in range(h // 4):
+            L.nrf_fft_process(shared, bufs[i])
+
+    threads = [threading.Thread(target=shared_object, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    out = L.nrf_fft_get_buffer(shared)
+    hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+    L.nut_buffer_free(out)
+    L.nrf_fft_free(shared)
+    counts = [0, 0, 0, 0]
+    for row in hist:                                            # every row is exactly one of the four spectra
+        d = [np.linalg.norm(row - w) / np.linalg.norm(w) for w in wants]
+        k = int(np.argmin(d))
+        assert d[k] < 1e-6, d
+        counts[k] += 1
+    assert counts == [h // 4] * 4, counts
+    for b in bufs:
+        L.nut_buffer_free(b)
