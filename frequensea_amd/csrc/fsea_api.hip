@@ -27,24 +27,19 @@ extern "C" int fsea_kernels_2048(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_4096(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_8192(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_16384(fsea::KernelEntry *out, int cap);
-extern "C" int fsea_kernels_var8192a(fsea::KernelEntry *out, int cap);
-extern "C" int fsea_kernels_var8192b(fsea::KernelEntry *out, int cap);
-extern "C" int fsea_kernels_varsmall(fsea::KernelEntry *out, int cap);
-extern "C" int fsea_kernels_varmid(fsea::KernelEntry *out, int cap);
-extern "C" int fsea_kernels_ablate(fsea::KernelEntry *out, int cap);
-extern "C" int fsea_kernels_exp(fsea::KernelEntry *out, int cap);
-extern "C" int fsea_kernels_exp2(fsea::KernelEntry *out, int cap);
+#ifdef FSEA_TUNE  // libfsea_hip_tune.so: the product kernels plus the tuning variants and ablations
+#include "../../include/fsea_tune.h"
+extern "C" int fsea_kernels_tune_8192a(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_8192b(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_abl(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_mid(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_big(fsea::KernelEntry *out, int cap);
+#endif
 
-#define FSEA_CTR_SLOTS 64u
+#define FSEA_CTR_SLOTS 64u          // ticket-counter slots = streams one plan may be launched on concurrently
 #define FSEA_CTR_WORDS (9u * 32u)  // 8 ticket pools + the finished-workgroups word, one 128-byte line each
 
 namespace {
-
-// Runs when the library is loaded: ask the HIP runtime to keep kernel arguments in device memory
-// (HIP_FORCE_DEV_KERNARG, read when HIP initialises).  With host-coherent kernargs the first scalar
-// load of every launch crosses PCIe, about 0.5 us of a 54 us launch and 1 us of an 18 us
-// nrf_fft_process call.  An explicit setting in the environment wins (no overwrite).
-__attribute__((constructor)) void fsea_runtime_defaults() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
 
 thread_local std::string g_last_error = "";
 
@@ -73,8 +68,11 @@ const std::vector<fsea::KernelEntry> &registry() {
         fsea::KernelEntry tmp[32];
         int (*lists[])(fsea::KernelEntry *, int) = {fsea_kernels_small, fsea_kernels_1024, fsea_kernels_2048,
                                                     fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384,
-                                                    fsea_kernels_var8192a, fsea_kernels_var8192b, fsea_kernels_varsmall,
-                                                    fsea_kernels_varmid, fsea_kernels_ablate, fsea_kernels_exp, fsea_kernels_exp2};
+#ifdef FSEA_TUNE
+                                                    fsea_kernels_tune_8192a, fsea_kernels_tune_8192b,
+                                                    fsea_kernels_tune_abl, fsea_kernels_tune_mid, fsea_kernels_tune_big,
+#endif
+        };
         for (auto fn : lists) {
             int n = fn(tmp, 32);
             for (int i = 0; i < n; ++i) v.push_back(tmp[i]);
@@ -101,6 +99,38 @@ size_t mode_elem_bytes(int mode) {
     default:
         return 4;
     }
+}
+
+// Every entry point works on the plan's device and leaves the caller's current device as it was
+// (a host process driving several GPUs, torch included, keeps its own notion of "current").
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+        else prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define FSEA_ON_DEVICE(dev)                                                                       \
+    DeviceGuard device_guard_(dev);                                                               \
+    if (device_guard_.err != hipSuccess) {                                                        \
+        return fail(FSEA_EHIP, "hipSetDevice(%d) failed: %s", (dev), hipGetErrorString(device_guard_.err)); \
+    }
+
+// which __global__ entry point serves (input kind, epilogue mode, byte convention)
+int pick_kind(int in_kind, int mode, int flip) {
+    if (in_kind == fsea::IN_F32) return fsea::K_F32;
+    if (in_kind == fsea::IN_U8_ROT) return fsea::K_U8_ROT;
+    if (flip && mode == FSEA_MODE_MAG_F32) return fsea::K_U8_MAG;
+    if (flip && mode == FSEA_MODE_DB5_U8_DCFIX) return fsea::K_U8_DB5;
+    if (flip && mode == FSEA_MODE_DB10_U8) return fsea::K_U8_DB10;
+    return fsea::K_U8;
 }
 
 __global__ void fsea_composite_max_kernel(uint8_t *dst, const uint8_t *src, uint32_t dst_x, uint32_t dst_y,
@@ -178,6 +208,16 @@ __global__ void fsea_sum_f32_kernel(const float *x, size_t n, double *acc) {
     }
 }
 
+// nrf_fft_shift on a device-resident history (src/nrf.c:569-596): every row moved by `shift` bins,
+// vacated bins zero; out of place (src and dst are the two halves of the ring's ping-pong storage).
+__global__ void fsea_history_shift_kernel(const float *src, float *dst, int n, size_t total, int shift) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % (size_t)n);
+        const int from = x + shift;
+        dst[i] = (from >= 0 && from < n) ? src[i - (size_t)x + (size_t)from] : 0.0f;
+    }
+}
+
 __global__ void fsea_f64_to_f32_kernel(const double *in, float *out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         out[i] = (float)in[i];
@@ -195,11 +235,17 @@ struct fsea_plan {
     hipStream_t stream = nullptr;
     fsea::cf *d_tw = nullptr;      // passes 1..np-1 concatenated
     size_t tw_off[5] = {0, 0, 0, 0, 0};  // passes 0..3, then the HI/LO factor tables (fsea_tables.h)
+    size_t tw_def_off = 0;               // deferred middle-pass table (OPT 128 / V2), 16-byte aligned
     int num_cu = 0;
-    unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x FSEA_CTR_WORDS ticket counters
-    std::atomic<unsigned> launch_seq{0};
-    unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics
-    int occ_u8_mag = 0, occ_u8 = 0, occ_f32 = 0, occ_u8_rot = 0;
+    // Ticket counters of the multi-wave sizes: one slot per stream the plan is launched on.  Launches
+    // on one stream run in order and the last workgroup of a launch zeroes its slot, so a stream
+    // needs exactly one; launches on different streams may overlap and never share one.
+    unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x FSEA_CTR_WORDS
+    std::mutex slot_mu;
+    hipStream_t slot_stream[FSEA_CTR_SLOTS] = {};
+    unsigned n_slots = 0;
+    unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics (tuning library)
+    int occ[fsea::K_COUNT] = {0, 0, 0, 0, 0, 0};
     // staging for the host-buffer entry points
     std::mutex mu;
     void *d_in = nullptr;
@@ -249,8 +295,8 @@ int ensure_pinned(void **ptr, size_t *cap, size_t need) {
     return FSEA_OK;
 }
 
-unsigned grid_for(const fsea_plan *p, int occ, size_t n_frames) {
-    const size_t units = (n_frames + p->entry->fpw - 1) / p->entry->fpw;
+unsigned grid_for(const fsea_plan *p, const fsea::KernelEntry *e, int occ, size_t n_frames) {
+    const size_t units = (n_frames + e->fpw - 1) / e->fpw;
     size_t g = (size_t)p->num_cu * (size_t)(occ > 0 ? occ : 1);
     if (units < g) g = units;
     if (g >= 8) g &= ~(size_t)7;  // the kernel's XCD-aware frame mapping wants a multiple of 8
@@ -258,15 +304,32 @@ unsigned grid_for(const fsea_plan *p, int occ, size_t n_frames) {
     return (unsigned)g;
 }
 
+// the ticket-counter slot of `s` (see fsea_plan::d_ctr), or null when the plan is already in use on
+// FSEA_CTR_SLOTS other streams
+unsigned *counter_slot(fsea_plan *p, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(p->slot_mu);
+    for (unsigned i = 0; i < p->n_slots; ++i) {
+        if (p->slot_stream[i] == s) return p->d_ctr + FSEA_CTR_WORDS * i;
+    }
+    if (p->n_slots == FSEA_CTR_SLOTS) return nullptr;
+    p->slot_stream[p->n_slots] = s;
+    return p->d_ctr + FSEA_CTR_WORDS * p->n_slots++;
+}
+
 int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
            hipStream_t s, double rot_delta = 0.0, double rot_phase0 = 0.0) {
     if (n_frames == 0) return FSEA_OK;
+    const int kind = pick_kind(in_kind, mode, flip);
+    const fsea::KernelEntry *e = p->entry;
+    if (!e->fn[kind]) {  // tuning variants carry the u8 MAG and run-time-mode kernels only
+        return fail(FSEA_EINVAL, "kernel variant '%s' has no entry point for this input kind", e->variant);
+    }
     fsea::FftArgs a;
     a.rot_delta = rot_delta;
     a.rot_phase0 = rot_phase0;
     if (in_kind == fsea::IN_U8_ROT) {
         fsea::TwPair rows[32];
-        fsea::build_rotation_rows(p->n, p->entry->radix[0], rot_delta, rows);
+        fsea::build_rotation_rows(p->n, e->radix[0], rot_delta, rows);
         for (int r = 0; r < 32; ++r) a.rot_row[r] = fsea::cf{rows[r].re, rows[r].im};
     }
     a.in = d_in;
@@ -275,17 +338,15 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.hop = (size_t)p->hop;
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
-    // every launch gets its own ticket-counter slot (zero on entry, reset by its last worker), so
-    // launches of one plan may overlap on different streams
-    a.ctr = p->d_ctr + FSEA_CTR_WORDS * (p->launch_seq.fetch_add(1) % FSEA_CTR_SLOTS);
+    a.ctr = counter_slot(p, s);
+    if (!a.ctr) {
+        return fail(FSEA_EINVAL, "plan is already in use on %u streams; create another plan for more", FSEA_CTR_SLOTS);
+    }
     a.trace = p->d_trace;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     a.tw_small = p->d_tw;
-    const int occ = (in_kind == fsea::IN_F32)      ? p->occ_f32
-                    : (in_kind == fsea::IN_U8_ROT) ? p->occ_u8_rot
-                    : (mode == FSEA_MODE_MAG_F32 && flip) ? p->occ_u8_mag  // the kernel the trampoline picks
-                                                          : p->occ_u8;
-    p->entry->launch(in_kind, a, grid_for(p, occ, n_frames), s);
+    a.tw_def = p->d_tw + p->tw_def_off;
+    e->launch(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
     FSEA_HIP(hipGetLastError());
     return FSEA_OK;
 }
@@ -312,14 +373,17 @@ int fsea_device_count(int *count) {
     return FSEA_OK;
 }
 
-int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, int device, const char *variant) {
+static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int device, const char *variant) {
     if (!out) return fail(FSEA_EINVAL, "plan out-pointer is NULL");
     *out = nullptr;
     if (mode < FSEA_MODE_MAG_F32 || mode > FSEA_MODE_DB_F32) return fail(FSEA_EINVAL, "unknown mode %d", mode);
     const fsea::KernelEntry *e = find_entry(fft_size, variant);
     if (!e) {
-        return fail(FSEA_EINVAL, "unsupported fft_size %d (variant '%s'): power of two in [128, 16384] required",
-                    fft_size, variant ? variant : "");
+        if (variant && variant[0]) {
+            return fail(FSEA_EINVAL, "no kernel variant '%s' for fft_size %d", variant, fft_size);
+        }
+        return fail(FSEA_EINVAL, "unsupported fft_size %d: the gfx950 kernels cover powers of two in [32, 16384] "
+                                 "(FFTW's other sizes have no kernel here)", fft_size);
     }
     if (hop <= 0 || (hop % 8) != 0) return fail(FSEA_EINVAL, "hop must be a positive multiple of 8 (got %d)", hop);
     int count = 0;
@@ -329,7 +393,7 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
                     hipGetErrorString(ce));
     }
     if (device < 0 || device >= count) return fail(FSEA_EINVAL, "device %d out of range [0,%d)", device, count);
-    FSEA_HIP(hipSetDevice(device));
+    FSEA_ON_DEVICE(device);
     hipDeviceProp_t prop;
     FSEA_HIP(hipGetDeviceProperties(&prop, device));
 
@@ -341,15 +405,24 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     p->device = device;
     p->entry = e;
     p->num_cu = prop.multiProcessorCount;
-    p->kernel_name = (mode == FSEA_MODE_MAG_F32) ? e->name_u8_mag : e->name_u8;
+    p->kernel_name = e->name[pick_kind(fsea::IN_U8, mode, 1)];  // the kernel raw int8 input (flip) launches
+#ifdef FSEA_TUNE
     if (std::getenv("FSEA_TRACE")) {
         if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 32 * sizeof(unsigned long long)) != hipSuccess) {
             p->d_trace = nullptr;
         }
     }
+#endif
 
     std::vector<fsea::TwPair> tw;
     fsea::build_twiddles(e->np, e->radix, tw, p->tw_off);
+    {
+        std::vector<fsea::TwPair> def;
+        fsea::build_deferred_table(e->radix[0], e->radix[1], def);
+        if (tw.size() & 1) tw.push_back(fsea::TwPair{0.f, 0.f});
+        p->tw_def_off = tw.size();
+        tw.insert(tw.end(), def.begin(), def.end());
+    }
     static_assert(sizeof(fsea::TwPair) == sizeof(fsea::cf), "twiddle layout");
     hipError_t he = hipMalloc(reinterpret_cast<void **>(&p->d_tw), tw.size() * sizeof(fsea::cf));
     if (he == hipSuccess) he = hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(fsea::cf), hipMemcpyHostToDevice);
@@ -357,12 +430,14 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_acc), sizeof(double));
     if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p->d_ctr), FSEA_CTR_SLOTS * FSEA_CTR_WORDS * sizeof(unsigned));
     if (he == hipSuccess) he = hipMemset(p->d_ctr, 0, FSEA_CTR_SLOTS * FSEA_CTR_WORDS * sizeof(unsigned));
+    // the memset runs on the null stream; the caller's (possibly non-blocking) streams are not ordered
+    // behind it, so it is complete before the plan is handed out
+    if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he == hipSuccess) he = hipEventCreate(&p->ev0);
     if (he == hipSuccess) he = hipEventCreate(&p->ev1);
-    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8_mag, e->fn_u8_mag, e->wg, 0);
-    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8, e->fn_u8, e->wg, 0);
-    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_f32, e->fn_f32, e->wg, 0);
-    if (he == hipSuccess) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ_u8_rot, e->fn_u8_rot, e->wg, 0);
+    for (int k = 0; k < fsea::K_COUNT && he == hipSuccess; ++k) {
+        if (e->fn[k]) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ[k], e->fn[k], e->wg, 0);
+    }
     if (he != hipSuccess) {
         int rc = fail(FSEA_EHIP, "plan setup failed: %s", hipGetErrorString(he));
         fsea_plan_destroy(p);
@@ -373,12 +448,27 @@ int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, i
 }
 
 int fsea_plan_create(fsea_plan **out, int fft_size, int hop, int mode, int device) {
-    return fsea_plan_create_variant(out, fft_size, hop, mode, device, "");
+    return create_plan(out, fft_size, hop, mode, device, "");
+}
+
+// Recovery: waits for the device and zeroes every ticket-counter slot (a launch that was aborted
+// leaves its slot non-zero, which would make later launches on that stream skip or repeat frames).
+int fsea_plan_reset(fsea_plan *p) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    FSEA_ON_DEVICE(p->device);
+    FSEA_HIP(hipDeviceSynchronize());
+    FSEA_HIP(hipMemset(p->d_ctr, 0, FSEA_CTR_SLOTS * FSEA_CTR_WORDS * sizeof(unsigned)));
+    FSEA_HIP(hipDeviceSynchronize());
+    {
+        std::lock_guard<std::mutex> lock(p->slot_mu);
+        p->n_slots = 0;
+    }
+    return FSEA_OK;
 }
 
 int fsea_plan_destroy(fsea_plan *p) {
     if (!p) return FSEA_OK;
-    (void)hipSetDevice(p->device);
+    DeviceGuard device_guard_(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_in) (void)hipFree(p->d_in);
@@ -400,17 +490,9 @@ size_t fsea_plan_row_bytes(const fsea_plan *p) { return p ? (size_t)p->n * mode_
 int fsea_plan_fft_size(const fsea_plan *p) { return p ? p->n : 0; }
 const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_name.c_str() : ""; }
 
-// Diagnostics (FSEA_TRACE=1): copies the [grid][32] trace words of the last launch.
-int fsea_plan_read_trace(fsea_plan *p, unsigned long long *out, unsigned n_workgroups) {
-    if (!p || !p->d_trace || n_workgroups > 4096) return fail(FSEA_EINVAL, "tracing is not enabled for this plan");
-    FSEA_HIP(hipSetDevice(p->device));
-    FSEA_HIP(hipMemcpy(out, p->d_trace, (size_t)n_workgroups * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return FSEA_OK;
-}
-
 int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned *block, size_t *lds_bytes) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
-    if (grid) *grid = grid_for(p, p->mode == FSEA_MODE_MAG_F32 ? p->occ_u8_mag : p->occ_u8, n_frames);
+    if (grid) *grid = grid_for(p, p->entry, p->occ[pick_kind(fsea::IN_U8, p->mode, 1)], n_frames);
     if (block) *block = (unsigned)p->entry->wg;
     if (lds_bytes) *lds_bytes = p->entry->lds_bytes;
     return FSEA_OK;
@@ -419,7 +501,7 @@ int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned
 int fsea_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, void *d_out, void *stream) {
     int rc = check_exec_args(p, d_iq, d_out, 16);
     if (rc) return rc;
-    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_ON_DEVICE(p->device);
     return launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, d_out,
                   static_cast<hipStream_t>(stream));
 }
@@ -433,7 +515,7 @@ int exec_u8_host(fsea_plan *p, int in_kind, const uint8_t *iq, size_t n_frames, 
     if (n_frames == 0) return FSEA_OK;
     if (!iq || !out) return fail(FSEA_EINVAL, "NULL buffer");
     std::lock_guard<std::mutex> lock(p->mu);
-    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_ON_DEVICE(p->device);
     const size_t in_bytes = 2 * ((n_frames - 1) * (size_t)p->hop + (size_t)p->n);
     const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
     if (in_bytes + out_bytes <= FSEA_ZERO_COPY_MAX) {
@@ -476,7 +558,7 @@ int fsea_exec_u8_shifted_device(fsea_plan *p, const void *d_iq, size_t n_frames,
     if (!std::isfinite(cycles_per_sample) || !std::isfinite(phase0_cycles)) {
         return fail(FSEA_EINVAL, "frequency shift must be finite");
     }
-    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_ON_DEVICE(p->device);
     return launch(p, fsea::IN_U8_ROT, d_iq, n_frames, flip, p->mode, d_out, static_cast<hipStream_t>(stream),
                   cycles_per_sample, phase0_cycles);
 }
@@ -494,7 +576,7 @@ int fsea_exec_f64_host(fsea_plan *p, const double *iq, size_t n_frames, void *ou
     if (n_frames == 0) return FSEA_OK;
     if (!iq || !out) return fail(FSEA_EINVAL, "NULL buffer");
     std::lock_guard<std::mutex> lock(p->mu);
-    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_ON_DEVICE(p->device);
     const size_t n_samples = (n_frames - 1) * (size_t)p->hop + (size_t)p->n;
     const size_t out_bytes = n_frames * fsea_plan_row_bytes(p);
     if (n_samples * 2 * sizeof(float) + out_bytes <= FSEA_ZERO_COPY_MAX) {
@@ -534,6 +616,137 @@ int fsea_exec_f64_host(fsea_plan *p, const double *iq, size_t n_frames, void *ou
     return FSEA_OK;
 }
 
+// ---- device-resident history ring (nrf_fft's history behind NRF_FFT_HISTORY=device) ----
+}  // extern "C"
+
+struct fsea_history {
+    fsea_plan *plan = nullptr;
+    int rows = 0;
+    int head = 0;             // ring row holding the newest spectrum
+    int cur = 0;              // which of the two storages is live (nrf_fft_shift works out of place)
+    float *d_ring[2] = {nullptr, nullptr};
+    float *h_stage = nullptr; // pinned, rows * n floats: target of the D2H in fsea_history_get_f64
+};
+
+namespace {
+
+// one frame from host memory, output row written straight into device memory
+int push_frame(fsea_history *h, int in_kind, const void *host_in, size_t in_bytes, int flip) {
+    fsea_plan *p = h->plan;
+    std::lock_guard<std::mutex> lock(p->mu);
+    FSEA_ON_DEVICE(p->device);
+    int rc = ensure_pinned(&p->h_in, &p->h_in_bytes, in_bytes);
+    if (rc) return rc;
+    void *d_in = nullptr;
+    FSEA_HIP(hipHostGetDevicePointer(&d_in, p->h_in, 0));
+    if (in_kind == fsea::IN_F32) {
+        const double *src = static_cast<const double *>(host_in);
+        float *dst = static_cast<float *>(p->h_in);
+        for (size_t i = 0; i < in_bytes / sizeof(float); ++i) dst[i] = (float)src[i];
+    } else {
+        std::memcpy(p->h_in, host_in, in_bytes);
+    }
+    const int new_head = (h->head + h->rows - 1) % h->rows;  // the ring head moves back by one
+    float *row = h->d_ring[h->cur] + (size_t)new_head * (size_t)p->n;
+    rc = launch(p, in_kind, d_in, 1, flip, FSEA_MODE_MAG_F32, row, p->stream);
+    if (rc) return rc;
+    FSEA_HIP(hipStreamSynchronize(p->stream));  // the staging is free again, the row is in place
+    h->head = new_head;
+    return FSEA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fsea_history_create(fsea_plan *p, int rows, fsea_history **out) {
+    if (!out) return fail(FSEA_EINVAL, "history out-pointer is NULL");
+    *out = nullptr;
+    if (!p || rows <= 0) return fail(FSEA_EINVAL, "history needs a plan and a positive row count");
+    if (p->mode != FSEA_MODE_MAG_F32) return fail(FSEA_EINVAL, "a history holds MAG_F32 rows");
+    FSEA_ON_DEVICE(p->device);
+    fsea_history *h = new (std::nothrow) fsea_history();
+    if (!h) return fail(FSEA_ENOMEM, "out of host memory");
+    h->plan = p;
+    h->rows = rows;
+    const size_t bytes = (size_t)rows * (size_t)p->n * sizeof(float);
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&h->d_ring[0]), bytes);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&h->d_ring[1]), bytes);
+    if (he == hipSuccess) he = hipMemset(h->d_ring[0], 0, bytes);
+    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void **>(&h->h_stage), bytes, hipHostMallocDefault);
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) {
+        int rc = fail(FSEA_EHIP, "history setup failed: %s", hipGetErrorString(he));
+        fsea_history_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return FSEA_OK;
+}
+
+int fsea_history_destroy(fsea_history *h) {
+    if (!h) return FSEA_OK;
+    DeviceGuard device_guard_(h->plan->device);
+    if (h->d_ring[0]) (void)hipFree(h->d_ring[0]);
+    if (h->d_ring[1]) (void)hipFree(h->d_ring[1]);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    delete h;
+    return FSEA_OK;
+}
+
+int fsea_history_push_u8_host(fsea_history *h, const uint8_t *iq, int flip) {
+    if (!h || !iq) return fail(FSEA_EINVAL, "NULL argument");
+    return push_frame(h, fsea::IN_U8, iq, 2 * (size_t)h->plan->n, flip);
+}
+
+int fsea_history_push_f64_host(fsea_history *h, const double *iq) {
+    if (!h || !iq) return fail(FSEA_EINVAL, "NULL argument");
+    return push_frame(h, fsea::IN_F32, iq, 2 * sizeof(float) * (size_t)h->plan->n, 0);
+}
+
+int fsea_history_shift(fsea_history *h, int shift) {
+    if (!h) return fail(FSEA_EINVAL, "history is NULL");
+    if (shift == 0) return FSEA_OK;
+    fsea_plan *p = h->plan;
+    std::lock_guard<std::mutex> lock(p->mu);
+    FSEA_ON_DEVICE(p->device);
+    const size_t total = (size_t)h->rows * (size_t)p->n;
+    if (shift >= p->n || shift <= -p->n) {  // shifted out of range: start over (src/nrf.c:574-576)
+        FSEA_HIP(hipMemsetAsync(h->d_ring[h->cur], 0, total * sizeof(float), p->stream));
+    } else {
+        unsigned blocks = (unsigned)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(fsea_history_shift_kernel, dim3(blocks), dim3(256), 0, p->stream, h->d_ring[h->cur],
+                           h->d_ring[h->cur ^ 1], p->n, total, shift);
+        FSEA_HIP(hipGetLastError());
+        h->cur ^= 1;
+    }
+    FSEA_HIP(hipStreamSynchronize(p->stream));
+    return FSEA_OK;
+}
+
+int fsea_history_get_f64(fsea_history *h, double *out) {
+    if (!h || !out) return fail(FSEA_EINVAL, "NULL argument");
+    fsea_plan *p = h->plan;
+    std::lock_guard<std::mutex> lock(p->mu);
+    FSEA_ON_DEVICE(p->device);
+    const size_t n = (size_t)p->n;
+    const size_t first = (size_t)(h->rows - h->head);  // rows from the head to the end of storage
+    const float *ring = h->d_ring[h->cur];
+    // one device-to-host transfer of rows * n f32, already in newest-first order, then one widening
+    FSEA_HIP(hipMemcpyAsync(h->h_stage, ring + (size_t)h->head * n, first * n * sizeof(float), hipMemcpyDeviceToHost,
+                            p->stream));
+    if (h->head > 0) {
+        FSEA_HIP(hipMemcpyAsync(h->h_stage + first * n, ring, (size_t)h->head * n * sizeof(float), hipMemcpyDeviceToHost,
+                                p->stream));
+    }
+    FSEA_HIP(hipStreamSynchronize(p->stream));
+    const size_t total = (size_t)h->rows * n;
+    const float *src = h->h_stage;
+    for (size_t i = 0; i < total; ++i) out[i] = (double)src[i];
+    return FSEA_OK;
+}
+
 int fsea_mean_magnitude_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, double *mean,
                                   void *stream) {
     if (!p || !mean) return fail(FSEA_EINVAL, "NULL argument");
@@ -543,7 +756,7 @@ int fsea_mean_magnitude_u8_device(fsea_plan *p, const void *d_iq, size_t n_frame
         return FSEA_OK;
     }
     std::lock_guard<std::mutex> lock(p->mu);
-    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_ON_DEVICE(p->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t count = n_frames * (size_t)p->n;
     int rc = ensure(&p->d_aux, &p->d_aux_bytes, count * sizeof(float));
@@ -566,8 +779,10 @@ int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x, ui
                               uint32_t height, uint32_t dst_stride, uint32_t src_stride, int device, void *stream) {
     if (!d_dst || !d_src) return fail(FSEA_EINVAL, "NULL buffer");
     if (width == 0 || height == 0) return FSEA_OK;
-    if (dst_x + width > dst_stride || width > src_stride) return fail(FSEA_EINVAL, "tile does not fit the row stride");
-    FSEA_HIP(hipSetDevice(device));
+    if ((uint64_t)dst_x + (uint64_t)width > (uint64_t)dst_stride || width > src_stride) {
+        return fail(FSEA_EINVAL, "tile does not fit the row stride");
+    }
+    FSEA_ON_DEVICE(device);
     const unsigned bx = 64;
     dim3 grid((width / 4 + bx) / bx, height < 4096 ? height : 4096);
     hipLaunchKernelGGL(fsea_composite_max_kernel, grid, dim3(bx), 0, static_cast<hipStream_t>(stream),
@@ -586,7 +801,7 @@ int fsea_stitch_tiles_device(void *d_image, const void *d_tiles, uint32_t n_tile
     if ((size_t)first_x + (size_t)(n_tiles - 1) * width_step + width > image_stride) {
         return fail(FSEA_EINVAL, "tiles do not fit the image row stride");
     }
-    FSEA_HIP(hipSetDevice(device));
+    FSEA_ON_DEVICE(device);
     // tiles k and k + m overlap when m * step < width: m phases keep every launch race-free
     const uint32_t phases = (width + width_step - 1) / width_step;
     const unsigned bx = 64;
@@ -604,34 +819,48 @@ int fsea_stitch_tiles_device(void *d_image, const void *d_tiles, uint32_t n_tile
 
 int fsea_device_alloc(int device, size_t bytes, void **d_ptr) {
     if (!d_ptr) return fail(FSEA_EINVAL, "NULL out-pointer");
-    FSEA_HIP(hipSetDevice(device));
+    FSEA_ON_DEVICE(device);
     FSEA_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
     return FSEA_OK;
 }
 
 int fsea_device_free(int device, void *d_ptr) {
     if (!d_ptr) return FSEA_OK;
-    FSEA_HIP(hipSetDevice(device));
+    FSEA_ON_DEVICE(device);
     FSEA_HIP(hipFree(d_ptr));
     return FSEA_OK;
 }
 
 int fsea_copy_to_device(int device, void *d_dst, const void *src, size_t bytes) {
-    FSEA_HIP(hipSetDevice(device));
+    FSEA_ON_DEVICE(device);
     FSEA_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
     return FSEA_OK;
 }
 
 int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes) {
-    FSEA_HIP(hipSetDevice(device));
+    FSEA_ON_DEVICE(device);
     FSEA_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return FSEA_OK;
 }
 
 int fsea_stream_synchronize(fsea_plan *p, void *stream) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
-    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_ON_DEVICE(p->device);
     FSEA_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return FSEA_OK;
+}
+
+#ifdef FSEA_TUNE
+// ---- tuning / measurement entry points (include/fsea_tune.h; libfsea_hip_tune.so only) ----
+int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, int device, const char *variant) {
+    return create_plan(out, fft_size, hop, mode, device, variant ? variant : "");
+}
+
+// Diagnostics (FSEA_TRACE=1): copies the [grid][32] trace words of the last launch.
+int fsea_plan_read_trace(fsea_plan *p, unsigned long long *out, unsigned n_workgroups) {
+    if (!p || !p->d_trace || n_workgroups > 4096) return fail(FSEA_EINVAL, "tracing is not enabled for this plan");
+    FSEA_ON_DEVICE(p->device);
+    FSEA_HIP(hipMemcpy(out, p->d_trace, (size_t)n_workgroups * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FSEA_OK;
 }
 
@@ -640,7 +869,7 @@ int fsea_time_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, in
     int rc = check_exec_args(p, d_iq, d_out, 16);
     if (rc) return rc;
     if (reps <= 0 || !avg_ms) return fail(FSEA_EINVAL, "reps must be > 0 and avg_ms non-NULL");
-    FSEA_HIP(hipSetDevice(p->device));
+    FSEA_ON_DEVICE(p->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     FSEA_HIP(hipEventRecord(p->ev0, s));
     for (int i = 0; i < reps; ++i) {
@@ -654,5 +883,6 @@ int fsea_time_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, in
     *avg_ms = ms / (float)reps;
     return FSEA_OK;
 }
+#endif  // FSEA_TUNE
 
 }  // extern "C"

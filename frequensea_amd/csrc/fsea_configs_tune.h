@@ -1,0 +1,59 @@
+// fsea_configs_tune.h -- tuning variants and measurement-only ablations, compiled into
+// libfsea_hip_tune.so only (fsea_plan_create_variant, include/fsea_tune.h); never product defaults.
+#pragma once
+
+#include "fsea_configs.h"
+
+// round-1 configurations of the sizes whose product configuration changed in round 2
+// (OPT 256: +-i butterflies as packed FMAs; no deferred twiddles)
+#define FSEA_CFG_8192_R1 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 286
+#define FSEA_CFG_16384_R1 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 264
+#define FSEA_CFG_1024_R1 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 266
+// packed-add +-i butterflies without the deferred twiddles
+#define FSEA_CFG_8192_ND 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 30
+#define FSEA_CFG_16384_ND 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 8
+// deferred twiddles on the sizes that did not gain from them
+#define FSEA_CFG_4096_DF 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 138
+#define FSEA_CFG_2048_DF 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 142
+// OPT 512 (late ticket wait) and OPT 1024 (static priority for one of the two co-resident workgroups)
+#define FSEA_CFG_8192_TK 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 670
+#define FSEA_CFG_8192_PR 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 1182
+// V2 schedule (OPT 64): first exchange inside each wavefront, two barriers per frame; with its
+// measurement-only ablations (8: static units + early prefetch, 16: V1 load mapping, wrong results,
+// 32: no first exchange, wrong results)
+#define FSEA_CFG_8192_V2 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 74
+#define FSEA_CFG_8192_V2S 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 8, 74
+#define FSEA_CFG_8192_V2L 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 16, 74
+#define FSEA_CFG_8192_V2SL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 24, 74
+#define FSEA_CFG_8192_V2NA 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 32, 74
+// other pass orders / twiddle sources
+#define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true
+#define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
+#define FSEA_CFG_8192_D 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true
+#define FSEA_CFG_8192_NOTWL 8192, 256, 1, 2, 3, 16, 32, 16, 1, false, true
+#define FSEA_CFG_8192_NOTWR 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, false
+#define FSEA_CFG_1024_B 1024, 64, 4, 4, 3, 16, 16, 4, 1, true, true
+#define FSEA_CFG_1024_C 1024, 64, 4, 4, 3, 4, 16, 16, 1, true, true
+#define FSEA_CFG_1024_D 1024, 32, 4, 2, 2, 32, 32, 1, 1, true, true
+#define FSEA_CFG_4096_B 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true
+#define FSEA_CFG_4096_C 4096, 128, 2, 2, 3, 16, 8, 32, 1, true, true
+#define FSEA_CFG_4096_D 4096, 128, 2, 2, 3, 8, 16, 32, 1, true, true
+#define FSEA_CFG_16384_B 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true
+#define FSEA_CFG_2048_B 2048, 64, 4, 2, 3, 8, 8, 32, 1, true, true
+#define FSEA_CFG_2048_C 2048, 64, 4, 2, 3, 4, 16, 32, 1, true, true
+// measurement-only ablations of the 8192-point kernel (results are wrong by design):
+// 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies, 64 = no per-frame loads,
+// 128 = no magnitude arithmetic
+#define FSEA_CFG_8192_NOST 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 1, 30
+#define FSEA_CFG_8192_NOLDS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 2, 30
+#define FSEA_CFG_8192_NOFLOP 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4, 30
+#define FSEA_CFG_8192_IO 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6, 30
+#define FSEA_CFG_8192_VALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 3, 30
+#define FSEA_CFG_8192_NOLOAD 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 64, 30
+#define FSEA_CFG_8192_NOMAG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 128, 30
+// schedule options of the defaults switched off (FftCfg::OPT), for A/B timing in one process
+#define FSEA_CFG_8192_X0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 0
+#define FSEA_CFG_8192_X7 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 7
+#define FSEA_CFG_4096_X0 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 0
+#define FSEA_CFG_2048_X0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 0
+#define FSEA_CFG_1024_X0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 0

@@ -79,22 +79,30 @@ __host__ __device__ constexpr float sin64(int m) { return cos64((m - 16) & 63); 
 __device__ __forceinline__ cf cf_swap(cf b) { return __builtin_shufflevector(b, b, 1, 0); }
 __device__ __forceinline__ cf cf_fma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
 
-// radix-2 butterfly with the constant twiddle w = exp(-2 pi i k / L) = (wr, wi):
-// (a, b) <- (a + w b, a - w b).  L and k are compile-time after unrolling.
+// radix-2 butterfly with the constant twiddle w = exp(-2 pi i K / L) = (wr, wi):
+// (a, b) <- (a + w b, a - w b).  L and K are template arguments: the +-i form is inline assembly,
+// and a branch around an asm statement is only removed when its condition is a constant expression.
 //   plus  = a + wr * b + (-wi, wi) * swap(b)      2 pk_fma (1 when wr == 0)
 //   minus = 2 a - plus                            1 pk_fma
-__device__ __forceinline__ void bfly_const(int L, int k, cf &a, cf &b) {
-    if (k == 0) {
+template <int L, int K, bool MI = true>
+__device__ __forceinline__ void bfly_const(cf &a, cf &b) {
+    if constexpr (K == 0) {
         const cf t = b;
         b = a - t;
         a = a + t;
-    } else if (4 * k == L) {  // w = -i : w b = (b.y, -b.x)
-        const cf sb = cf_swap(b);
-        b = cf_fma(sb, cf{-1.0f, 1.0f}, a);
-        a = cf_fma(sb, cf{1.0f, -1.0f}, a);
+    } else if constexpr (4 * K == L) {  // w = -i : w b = (b.y, -b.x)
+        if constexpr (MI) {
+            const cf t = b;
+            b = pk_add_pi(a, t);
+            a = pk_add_mi(a, t);
+        } else {  // the round-1 form: two packed FMAs with (+-1, -+1)
+            const cf sb = cf_swap(b);
+            b = cf_fma(sb, cf{-1.0f, 1.0f}, a);
+            a = cf_fma(sb, cf{1.0f, -1.0f}, a);
+        }
     } else {
-        const int m = k * (64 / L);
-        const float wr = cos64(m), wi = -sin64(m);
+        constexpr int m = K * (64 / L);
+        constexpr float wr = cos64(m), wi = -sin64(m);
         cf plus = cf_fma(b, cf{wr, wr}, a);
         plus = cf_fma(cf_swap(b), cf{-wi, wi}, plus);
         b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
@@ -102,9 +110,26 @@ __device__ __forceinline__ void bfly_const(int L, int k, cf &a, cf &b) {
     }
 }
 
+// one level of the constant-twiddle DFT: butterflies (base + k, base + k + HALF), k < HALF
+template <int R, int HALF, bool MI, int BASE = 0, int K = 0>
+__device__ __forceinline__ void dft_const_level(cf *y) {
+    if constexpr (BASE < R) {
+        bfly_const<2 * HALF, K, MI>(y[BASE + K], y[BASE + K + HALF]);
+        if constexpr (K + 1 < HALF) dft_const_level<R, HALF, MI, BASE, K + 1>(y);
+        else dft_const_level<R, HALF, MI, BASE + 2 * HALF, 0>(y);
+    }
+}
+template <int R, int HALF, bool MI>
+__device__ __forceinline__ void dft_const_levels(cf *y) {
+    if constexpr (HALF < R) {
+        dft_const_level<R, HALF, MI>(y);
+        dft_const_levels<R, 2 * HALF, MI>(y);
+    }
+}
+
 // R-point DFT (forward, -1 exponent) over x[0], x[S], ..., x[(R-1)S];
 // natural order in and out.  Bit reversal is register renaming only.
-template <int R, int S, bool SKIP = false>
+template <int R, int S, bool SKIP = false, bool MI = true>
 __device__ __forceinline__ void dft_regs(cf *x) {
     if constexpr (SKIP) return;
     static_assert(R >= 2 && R <= 64 && (R & (R - 1)) == 0, "radix must be 2..64");
@@ -112,16 +137,7 @@ __device__ __forceinline__ void dft_regs(cf *x) {
     cf y[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) y[bitrev_c(i, BITS)] = x[i * S];
-#pragma unroll
-    for (int half = 1; half < R; half <<= 1) {
-#pragma unroll
-        for (int base = 0; base < R; base += 2 * half) {
-#pragma unroll
-            for (int k = 0; k < half; ++k) {
-                bfly_const(2 * half, k, y[base + k], y[base + k + half]);
-            }
-        }
-    }
+    dft_const_levels<R, 1, MI>(y);
 #pragma unroll
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
@@ -132,7 +148,7 @@ __device__ __forceinline__ void dft_regs(cf *x) {
 //   minus = 2 a - plus                                  1 pk_fma
 // i.e. 5 packed ops per pair instead of 6 (3 instead of 4 for the untwiddled row 0).
 // SC0: scale applied to row 0 (the other rows carry it in their twiddles), 1 = none.
-template <int R, int S, int TS>
+template <int R, int S, int TS, bool MI = true>
 __device__ __forceinline__ void dft_regs_tw(cf *x, const cf *tw, float sc0) {
     static_assert(R >= 4 && R <= 64 && (R & (R - 1)) == 0, "radix must be 4..64");
     constexpr int BITS = ilog2c(R);
@@ -149,16 +165,54 @@ __device__ __forceinline__ void dft_regs_tw(cf *x, const cf *tw, float sc0) {
         y[bitrev_c(i, BITS)] = plus;
         y[bitrev_c(i + R / 2, BITS)] = cf_fma(a, cf{2.0f, 2.0f}, -plus);
     }
+    dft_const_levels<R, 2, MI>(y);
 #pragma unroll
-    for (int half = 2; half < R; half <<= 1) {
+    for (int i = 0; i < R; ++i) x[i * S] = y[i];
+}
+
+// The same twiddled DFT with the inter-pass twiddles deferred into the butterfly levels
+// (polynomial form): with x_i scaled by om^i (om = W^k, one value per lane), y_k = P(om W_R^k),
+// P(z) = sum x_i z^i = E(z^2) + z O(z^2).  The level that merges sub-transforms of size `half`
+// then uses the twiddles om^{R/(2 half)} W_{2 half}^j, j < half, of which the upper half is -i
+// times the lower one: R/2 run-time twiddles per lane instead of R-1, every butterfly the
+// general 3-op form (plus = a + w b in two packed FMAs, minus = 2a - plus in one) -- the same
+// 3 R log2 R / 2 packed ops as dft_regs_tw.
+// tw layout: [om^{R/2}] [om^{R/4}] [om^{R/8} W_8^{0,1}] [om^{R/16} W_16^{0..3}] ... (fsea_tables.h).
+template <int R, int HALF, int TS>
+__device__ __forceinline__ void dft_def_level(cf *y, const cf *tw) {
+    if constexpr (HALF < R) {
+        constexpr int OFF = HALF / 2, DISTINCT = HALF >= 2 ? HALF / 2 : 1;
 #pragma unroll
-        for (int base = 0; base < R; base += 2 * half) {
+        for (int base = 0; base < R; base += 2 * HALF) {
 #pragma unroll
-            for (int k = 0; k < half; ++k) {
-                bfly_const(2 * half, k, y[base + k], y[base + k + half]);
+            for (int k = 0; k < DISTINCT; ++k) {
+                cf &a = y[base + k], &b = y[base + k + HALF];
+                const cf plus = pk_cmul_add(b, tw[(OFF + k) * TS], a);
+                b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
+                a = plus;
+            }
+            if constexpr (HALF >= 2) {
+#pragma unroll
+                for (int k = 0; k < DISTINCT; ++k) {
+                    cf &a = y[base + DISTINCT + k], &b = y[base + DISTINCT + k + HALF];
+                    const cf plus = pk_cmul_add_mi(b, tw[(OFF + k) * TS], a);
+                    b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
+                    a = plus;
+                }
             }
         }
+        dft_def_level<R, 2 * HALF, TS>(y, tw);
     }
+}
+
+template <int R, int S, int TS>
+__device__ __forceinline__ void dft_regs_def(cf *x, const cf *tw) {
+    static_assert(R >= 4 && R <= 64 && (R & (R - 1)) == 0, "radix must be 4..64");
+    constexpr int BITS = ilog2c(R);
+    cf y[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) y[bitrev_c(i, BITS)] = x[i * S];
+    dft_def_level<R, 1, TS>(y, tw);
 #pragma unroll
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
@@ -178,6 +232,11 @@ enum : int { IN_U8 = 0, IN_F32 = 1, IN_U8_ROT = 2 };  // IN_U8_ROT: launch selec
 
 #ifndef FSEA_DEFAULT_OPT
 #define FSEA_DEFAULT_OPT 0
+#endif
+// Per-workgroup time stamps (FftArgs::trace) are compiled into the tuning library only
+// (libfsea_hip_tune.so, -DFSEA_TRACE=1); the product kernels carry no trace code.
+#ifndef FSEA_TRACE
+#define FSEA_TRACE 0
 #endif
 
 // N: transform size; T: threads per frame; FPW: frames per workgroup;
@@ -201,6 +260,12 @@ struct FftCfg {
     //     per instruction; scripts/lds_conflicts.py); rotated, the groups are conflict-free;
     // 32 = the same renumbering for the last pass (and the cross-block form for 8-byte layouts, see
     //     pass_lane); measured null, off everywhere.
+    // 128 = the middle pass's twiddles are deferred into the butterflies (dft_regs_def) and kept in
+    //     registers for the workgroup's lifetime: R/2 pairs per column instead of R-1 LDS reads per frame;
+    // 256 = the +-i butterflies as packed FMAs by (+-1, -+1) instead of packed adds (the round-1 form);
+    // 512 = ticket sizes: the ticket word is waited for behind pass 1's LDS reads, not in front of them;
+    // 64 = the V2 schedule (run_v2): first exchange inside each wavefront, two barriers per frame,
+    //     middle-pass twiddles deferred into the butterflies and kept in registers.
     static constexpr int OPT = OPT_;
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
     // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
@@ -223,7 +288,7 @@ struct FftCfg {
     // small twiddle block kept in LDS: middle-pass tables, then the two factor tables
     // HI[N/64] = W^{64 h}, LO[64] = W^{l} the last pass's register twiddles are built from
     static constexpr int TAB_MID = lds_tw_off(NP_ - 1) - FPW_ * LDS_FRAME;
-    static constexpr int TAB_HI = N_ / 64, TAB_LO = 64;
+    static constexpr int TAB_HI = N_ >= 64 ? N_ / 64 : 1, TAB_LO = 64;
     static constexpr int TAB_SMALL = TAB_MID + (TWR_ ? TAB_HI + TAB_LO : 0);
     static constexpr int LDS_HI = FPW_ * LDS_FRAME + TAB_MID;
     static constexpr int LDS_LO = LDS_HI + TAB_HI;
@@ -245,6 +310,7 @@ struct FftArgs {
     unsigned long long *trace;  // diagnostics: [grid][32] = wall start/end, shader-clock start/end, HW_ID, XCC_ID, -, -, end of iteration 0..23; or null
     const cf *tw[4];      // tw[i]: pass-i table, (R_i-1)*Ns_i entries, [r-1][k]
     const cf *tw_small;   // [middle-pass tables | HI | LO], the block copied to LDS (fsea_tables.h)
+    const cf *tw_def;     // V2 schedule: deferred middle-pass twiddles, [R0][R1/2] (build_deferred_table)
     // frequency-shifted input (ROT kernels only; fsea_exec_u8_shifted_*): stream sample m is
     // multiplied by e^{2 pi i (rot_phase0 + m rot_delta)}, both in turns.  rot_row[r] =
     // e^{2 pi i rot_delta r N / R0}, the factor between the pass-0 rows of one lane.
@@ -447,6 +513,9 @@ struct FftKernel {
     static constexpr bool BATCH_READS = (Cfg::OPT & 2) != 0;
     static constexpr bool TW_HOIST = (Cfg::OPT & 4) != 0;
     static constexpr bool TW_FUSE = (Cfg::OPT & 8) != 0 && (Cfg::ABL & 4) == 0;
+    static constexpr bool DEFER = (Cfg::OPT & 128) != 0 && NP == 3;
+    static constexpr bool TK_LATE = (Cfg::OPT & 512) != 0 && NP >= 3 && !ONE_WAVE && (Cfg::ABL & 2) == 0;
+    static constexpr bool MI = (Cfg::OPT & 256) == 0;  // OPT 256: the +-i butterflies as packed FMAs by (+-1, -+1) (round-1 form)
     static constexpr bool LANE_ROT = (Cfg::OPT & 16) != 0;       // middle passes
     static constexpr bool LANE_ROT_LAST = (Cfg::OPT & 32) != 0;  // the last pass as well
     // Which frame-lane a physical lane works as in pass I >= 1.  Any bijection is valid: passes meet
@@ -623,24 +692,38 @@ struct FftKernel {
     }
 
     // middle pass I (1 <= I < LAST): read, twiddle, DFT, write back
-    template <int I>
-    static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t0) {
+    // issued(): called once, right behind the LDS reads of pass 1 (OPT 512: the ticket and the next
+    // unit's loads are handled there, so that the reads are in flight before the ticket is waited for)
+    struct NoHook {
+        __device__ __forceinline__ void operator()() const {}
+    };
+    template <int I, class Hook = NoHook>
+    static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t0,
+                                                       const cf *tw_res = nullptr, Hook &&issued = Hook()) {
         if constexpr (I < LAST) {
             constexpr int R = Cfg::R(I), C = Cfg::C(I);
             const int t = pass_lane<I>(t0);
             const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
-            if constexpr (TW_HOIST && (Cfg::Ns(I) % C == 0)) {
+            if constexpr (DEFER) {
+                lds_read<I>(lds, v, t);
+                if constexpr (I == 1) issued();
+                after_reads();
+                if constexpr (!LAZY_SYNC) frame_sync();
+#pragma unroll
+                for (int c = 0; c < C; ++c) dft_regs_def<R, C, 1>(v + c, tw_res + c * (R / 2));
+            } else if constexpr (TW_HOIST && (Cfg::Ns(I) % C == 0)) {
                 constexpr int Ns = Cfg::Ns(I);
                 cf w[(R - 1) * C];
                 const int k0 = (C * t) % Ns;
 #pragma unroll
                 for (int r = 1; r < R; ++r) ld_c<C>(tw + (r - 1) * Ns + k0, w + (r - 1) * C);
                 lds_read<I>(lds, v, t);
+                if constexpr (I == 1) issued();
                 after_reads();
                 if constexpr (!LAZY_SYNC) frame_sync();
                 if constexpr (TW_FUSE) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) dft_regs_tw<R, C, C>(v + c, w + c, 1.0f);
+                    for (int c = 0; c < C; ++c) dft_regs_tw<R, C, C, MI>(v + c, w + c, 1.0f);
                 } else {
 #pragma unroll
                     for (int r = 1; r < R; ++r) {
@@ -650,18 +733,19 @@ struct FftKernel {
                 }
             } else {
                 lds_read<I>(lds, v, t);
+                if constexpr (I == 1) issued();
                 after_reads();
                 if constexpr (!LAZY_SYNC) frame_sync();  // everyone has read before anyone overwrites
                 apply_twiddles<I>(v, tw, t);
             }
-            if constexpr (!(TW_FUSE && TW_HOIST && (Cfg::Ns(I) % C == 0))) {
+            if constexpr (!DEFER && !(TW_FUSE && TW_HOIST && (Cfg::Ns(I) % C == 0))) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0>(v + c);
+                for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0, MI>(v + c);
             }
             if constexpr (LAZY_SYNC) lazy_sync();  // same barrier, after this wave's butterflies
             lds_write<I>(lds, v, t);
             frame_sync();
-            middle_pass<I + 1>(lds, lds_all, v, a, t0);
+            middle_pass<I + 1>(lds, lds_all, v, a, t0, tw_res);  // further middle passes: no hook
         }
     }
 
@@ -735,6 +819,8 @@ struct FftKernel {
                     if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
                     if (mode == MODE_DB_F32) {
                         m[c] = (10.0f * 0.30102999566398120f) * __builtin_amdgcn_logf(p + 1.0e-20f);
+                    } else if constexpr (Cfg::ABL & 128) {  // ABL 128 (measurement only): no magnitude arithmetic
+                        m[c] = z[0];
                     } else {
                         m[c] = __builtin_amdgcn_sqrtf(p);
                     }
@@ -782,7 +868,283 @@ struct FftKernel {
         }
     };
 
+    static constexpr bool V2 = (Cfg::OPT & 64) != 0;
+
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
+        if constexpr (V2) run_v2(a, lds_all);
+        else run_v1(a, lds_all);
+    }
+
+    // -----------------------------------------------------------------------------------------
+    // V2 schedule for frames spread over several wavefronts (three passes RA x RB x RC).
+    //
+    // Sample index n = a N/RA + b RC + c, bin k = ka + RA kb + RA RB kc:
+    //   pass 0 sums over a (-> ka), twiddle W_{RA RB}^{b ka}, pass 1 over b (-> kb), twiddle
+    //   W_N^{c (ka + RA kb)}, pass 2 over c (-> kc).
+    // Only the bits a lane holds in registers are forced (a, b, c in turn); which of the other
+    // bits are lane bits and which are wave bits is free.  V1 takes them in Stockham order, which
+    // makes both exchanges cross-wave: two s_barriers each.  Here the wave bits of passes 0 and 1
+    // are the top bits of c, so the first exchange (ka <-> b) stays inside a wavefront -- LDS
+    // operations of one wave execute in order, no barrier -- and only the second one crosses
+    // waves.  Every element of that second exchange is read by exactly one wave, so the buffer
+    // is a partition S_w by reading wave; once wave w has read its S_w nobody else touches it
+    // until the next cross-wave write, and w runs its own first exchange of the next frame in
+    // it.  Per frame: [pass 0] A-write A-read [pass 1] BARRIER B-write BARRIER B-read [pass 2]:
+    // two barriers instead of four, one rendezvous per frame.
+    //   * Pass-0 loads: a wave reads 16-byte pieces at 64-byte stride (its c bits), the four
+    //     waves of the workgroup cover the lines between them (L1 hits); stores keep 256-byte runs.
+    //   * Middle-pass twiddles W_{RA RB}^{b ka} depend on the lane (ka) only: deferred into the
+    //     butterflies (dft_regs_def) they are RB/2 register pairs per lane, resident for the
+    //     workgroup's lifetime; no twiddle is read from LDS per frame.
+    // LDS slots are 16 bytes (two complex, the c0 pair):
+    //   A (inside S_w): slot = 65 ka + 16 g + b      writer lane (b, g), reader lane (ka, g)
+    //   B:              slot = 17 m + j              m = ka + RA kb, j = c / 2; S_w = rows 64 w ..
+    // both conflict-free for ds_write_b128 (8 consecutive lanes -> 8 consecutive slots mod 8) and
+    // ds_read_b128 (a 16-lane group -> 16 distinct slots mod 16; 65 and 17 are odd).
+    // -----------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void wave_order() {
+        // LDS operations of one wavefront execute in program order; this only stops the compiler
+        // from moving them across (and keeps the CPU emulation's lanes together)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    static __device__ __forceinline__ void run_v2(const FftArgs &a, cf *lds_all) {
+        constexpr int RA = Cfg::R(0), RB = Cfg::R(1), RC = Cfg::R(2);
+        static_assert(NP == 3 && FPW == 1 && (T % 64) == 0 && !ONE_WAVE, "V2 is for multi-wave frames in three passes");
+        static_assert(RA == 16 && RB == 16 && RC == 32 && P == 32, "V2 layout constants are written for 16 x 16 x 32");
+        static_assert(Cfg::TWR, "V2 keeps the last pass's twiddles in registers");
+        constexpr int G = 64 / RB;            // lane groups per wave (the c bits below the wave bits, above c0)
+        constexpr int ROW_B = RC / 2 + 1;     // 16-byte slots per B row (m), odd
+        constexpr int SW = 64 * ROW_B;        // slots of one wave's partition S_w
+        constexpr int ROW_A = 4 * RB + 1;     // slots between consecutive ka in the A layout, odd
+        static_assert((RA - 1) * ROW_A + 16 * (G - 1) + RB <= SW, "the A layout must fit the wave's partition");
+        static_assert(2 * SW * (T / 64) <= Cfg::LDS_FRAME, "LDS frame too small for the B layout");
+
+        const int tid = threadIdx.x;
+        const int w = tid >> 6, l = tid & 63;
+        unsigned *tk = reinterpret_cast<unsigned *>(lds_all + Cfg::LDS_TOTAL);
+        cf *lds = lds_all;
+
+        const unsigned bidx = blockIdx.x;
+        const bool issuer = (tid == 0);
+        const size_t n_units = a.n_frames;
+        Pools pools;
+        pools.n_units = (unsigned)n_units;
+        pools.grid = gridDim.x;
+        unsigned cur = bidx % POOLS;
+
+        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) {
+            const unsigned hw_id = read_hw_id(), xcc_id = read_xcc_id();
+            a.trace[32 * bidx + 0] = wall_clock64();
+            a.trace[32 * bidx + 2] = __builtin_readcyclecounter();
+            a.trace[32 * bidx + 4] = hw_id;
+            a.trace[32 * bidx + 5] = xcc_id;
+        }
+
+        const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
+        const uint32_t xormask = (MODE_T >= 0) ? 0u : a.xormask;
+        const uint32_t esz = elem_bytes(mode);
+        const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
+        const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
+        // pass 0: lane (b, g) of wave w holds samples n = a N/RA + b RC + (w G + g) C0 + c0
+        const int b0 = l % RB, g = l / RB;
+        const int n_base = b0 * RC + (w * G + g) * C0;
+        // ABL 16 (measurement only, wrong results): the V1 load mapping, 256-byte runs per wave
+        const uint32_t in_voff = (uint32_t)IN_BPS * (uint32_t)((Cfg::ABL & 16) ? C0 * tid : n_base);
+        // ABL 8 (measurement only): static unit interleave, next unit's bytes requested right after the
+        // conversion of this one's
+        constexpr bool STATIC = (Cfg::ABL & 8) != 0;
+        // pass 1: lane (ka, g); pass 2: thread m = ka + RA kb = tid
+        const int ka = l % RA;
+        const int m = tid;
+        const uint32_t out_elem = (uint32_t)m;
+
+        size_t u = (size_t)pools.start(cur) + bidx / POOLS;
+        if (u >= pools.start(cur + 1)) u = n_units;
+        if constexpr (STATIC) u = bidx;
+        unsigned tick_next = 0;
+
+        constexpr int TAB_COPY = Cfg::TAB_SMALL;
+        constexpr int TAB_REGS = (TAB_COPY + Cfg::WG - 1) / Cfg::WG;
+        cf tabv[TAB_REGS];
+#pragma unroll
+        for (int i = 0; i < TAB_REGS; ++i) {
+            const int e = tid + i * Cfg::WG;
+            tabv[i] = a.tw_small[e < TAB_COPY ? e : TAB_COPY - 1];
+        }
+        // this lane's deferred middle-pass twiddles: RB/2 pairs, resident
+        cf tw1[RB / 2];
+        ld_c<RB / 2>(a.tw_def + ka * (RB / 2), tw1);
+        Raw raw[R0];
+        load_raw(buffer_window(a.in, (size_t)IN_BPS * u * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+        if (!STATIC && issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+
+#pragma unroll
+        for (int i = 0; i < TAB_REGS; ++i) {
+            const int e = tid + i * Cfg::WG;
+            lds_all[Cfg::LDS_FRAME + (e < TAB_COPY ? e : TAB_COPY - 1)] = tabv[i];
+        }
+        __syncthreads();
+        cf twl[(RL - 1) * CL];
+        {
+            const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
+#pragma unroll
+            for (int r = 1; r < RL; ++r) {
+                const unsigned e = (unsigned)r * (unsigned)m;
+                cf tw = pk_cmul(hi[e >> 6], lo[e & 63u]);
+                if constexpr (PRESCALED) tw = tw * cf{SC, SC};
+                twl[r - 1] = tw;
+            }
+        }
+
+        cf ebase[ROT ? C0 : 1];
+        if constexpr (ROT) {
+#pragma unroll
+            for (int c = 0; c < C0; ++c) {
+                const unsigned n0 = (unsigned)(n_base + c);
+                const cf e = turn_phasor_f64(a.rot_delta * (double)n0);
+                ebase[c] = (n0 & 1u) ? -e : e;
+            }
+        }
+
+        unsigned par = 0;
+        if (!STATIC && u >= n_units) {
+            if (issuer) {
+                unsigned nu = pools.unit(cur, tick_next);
+                for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
+                    const unsigned q = (cur + k) % POOLS;
+                    nu = pools.unit(q, atomicAdd(a.ctr + 32 * q, 1u));
+                    if (nu != NO_UNIT) cur = q;
+                }
+                tk[0] = nu;
+                tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+            }
+            __syncthreads();
+            const unsigned nu = __builtin_amdgcn_readfirstlane(tk[0]);
+            __syncthreads();
+            u = (nu == NO_UNIT) ? n_units : (size_t)nu;
+            load_raw(buffer_window(a.in, (size_t)IN_BPS * u * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+        }
+
+        // LDS addresses (complex units; a slot is two complex)
+        cf *const sw = lds + 2 * SW * w;                                   // this wave's partition
+        cf *const a_wr = sw + 2 * (16 * g + b0);                           // + 2 ROW_A ka
+        const cf *const a_rd = sw + 2 * (ROW_A * ka + 16 * g);             // + 2 b
+        cf *const b_wr = lds + 2 * (ROW_B * ka + (w * G + g));             // + 2 ROW_B RA kb
+        const cf *const b_rd = lds + 2 * ROW_B * m;                        // + 2 j
+
+        unsigned iter = 0;
+        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) a.trace[32 * bidx + 6] = wall_clock64();
+        while (u < n_units) {
+            if (!STATIC && issuer) {
+                unsigned nu = pools.unit(cur, tick_next);
+                for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
+                    const unsigned q = (cur + k) % POOLS;
+                    nu = pools.unit(q, atomicAdd(a.ctr + 32 * q, 1u));
+                    if (nu != NO_UNIT) cur = q;
+                }
+                tk[par] = nu;
+                tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+            }
+
+            cf v[P];
+            if constexpr (ROT) {
+                const size_t first = u * a.hop;
+                const cf ef = turn_phasor_f32(a.rot_phase0 + a.rot_delta * (double)first);
+                cf fr[C0];
+#pragma unroll
+                for (int c = 0; c < C0; ++c) fr[c] = pk_cmul(ebase[c], ef);
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    convert_row<IN, C0, false>(raw[r], a.xormask, n_base, v + r * C0);
+                    const cf wr = a.rot_row[r];
+#pragma unroll
+                    for (int c = 0; c < C0; ++c) {
+                        v[r * C0 + c] = pk_cmul(v[r * C0 + c] + cf{128.0f, 128.0f}, pk_cmul_uniform(fr[c], wr));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], xormask, n_base, v + r * C0);
+            }
+            size_t un = u + gridDim.x;
+            if constexpr (STATIC) {
+                load_raw(buffer_window(a.in, (size_t)IN_BPS * un * a.hop, un < n_units ? total_in : 0), in_voff, raw);
+            }
+#pragma unroll
+            for (int c = 0; c < C0; ++c) dft_regs<R0, C0>(v + c);
+
+            // exchange A, inside this wave's partition: ka <-> b
+            if constexpr ((Cfg::ABL & 32) == 0) {  // ABL 32 (measurement only): no exchange A
+                wave_order();  // this wave's reads of the previous frame (B) precede these writes
+#pragma unroll
+                for (int r = 0; r < RA; ++r) st_c<2>(a_wr + 2 * ROW_A * r, v + 2 * r);
+                wave_order();
+#pragma unroll
+                for (int r = 0; r < RB; ++r) ld_c<2>(a_rd + 2 * r, v + 2 * r);
+                after_reads();
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) dft_regs_def<RB, 2, 1>(v + c, tw1);
+
+            __syncthreads();  // every wave has read its partition: the cross-wave writes may land
+            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * bidx + 7] = wall_clock64();
+            // exchange B, across waves: row m = ka + RA kb gets this lane's c pair at j = w G + g
+#pragma unroll
+            for (int r = 0; r < RB; ++r) st_c<2>(b_wr + 2 * ROW_B * RA * r, v + 2 * r);
+            __syncthreads();
+            // nothing but the writes sits between the two barriers; the ticket word is read in
+            // front of the data (LDS returns in order), and the next unit's bytes are requested
+            // while the rows come in
+            const unsigned tkv = STATIC ? 0u : tk[par];
+#pragma unroll
+            for (int j = 0; j < RC / 2; ++j) ld_c<2>(b_rd + 2 * j, v + 2 * j);
+            if constexpr (!STATIC) {
+                __builtin_amdgcn_sched_barrier(0);  // the reads are issued before the ticket is waited for
+                const unsigned nu = __builtin_amdgcn_readfirstlane(tkv);
+                par ^= 1u;
+                un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+                load_raw(buffer_window(a.in, (size_t)IN_BPS * un * a.hop, un < n_units ? total_in : 0), in_voff, raw);
+            }
+            after_reads();
+
+            if constexpr (TW_FUSE) {
+                dft_regs_tw<RL, 1, 1>(v, twl, PRESCALED ? SC : 1.0f);
+            } else {
+                if constexpr (PRESCALED) v[0] = v[0] * cf{SC, SC};
+#pragma unroll
+                for (int r = 1; r < RL; ++r) v[r] = pk_cmul(v[r], twl[r - 1]);
+                dft_regs<RL, 1>(v);
+            }
+            epilogue(mode, buffer_window(a.out, (size_t)esz * u * (size_t)N, total_out), out_elem, v, m);
+            u = un;
+            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * bidx + 8 + iter] = wall_clock64();
+            ++iter;
+        }
+
+        if (!STATIC && issuer) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned finished = atomicAdd(a.ctr + 32 * POOLS, 1u);
+            if (finished == gridDim.x - 1) {
+#pragma unroll
+                for (unsigned q = 0; q <= POOLS; ++q) a.ctr[32 * q] = 0;
+            }
+        }
+        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) {
+            a.trace[32 * bidx + 1] = wall_clock64();
+            a.trace[32 * bidx + 3] = __builtin_readcyclecounter();
+        }
+    }
+
+    static __device__ __forceinline__ void run_v1(const FftArgs &a, cf *lds_all) {
+        // OPT 1024: static priority for the second resident workgroup of every CU (blocks are placed
+        // round-robin, so block b and b + grid/2 share a CU): one of the two co-resident waves of a
+        // SIMD always wins the VALU, the other fills its gaps
+        if constexpr ((Cfg::OPT & 1024) != 0) {
+            if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(1);
+        }
         const int tid = threadIdx.x;
         const int slot = (FPW == 1) ? 0 : tid / T;  // frame index inside the unit = LDS region
         const int t = (FPW == 1) ? tid : tid % T;
@@ -797,7 +1159,7 @@ struct FftKernel {
         pools.grid = gridDim.x;
         unsigned cur = b % POOLS;  // pool this workgroup is drawing from (issuer lane only)
 
-        if (a.trace != nullptr && tid == 0) {
+        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) {
             const unsigned hw_id = read_hw_id(), xcc_id = read_xcc_id();
             a.trace[32 * b + 0] = wall_clock64();
             a.trace[32 * b + 2] = __builtin_readcyclecounter();
@@ -806,9 +1168,10 @@ struct FftKernel {
         }
 
         const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
-        // the compile-time MAG kernel is the raw-int8 (HackRF, flip) path: its bytes are the signed
-        // samples already, no XOR; offset-binary input goes through the run-time-mode kernel
-        const uint32_t xormask = (MODE_T == MODE_MAG) ? 0u : a.xormask;
+        // the compile-time-mode kernels (MAG, DB5, DB10) are the raw-int8 (HackRF, flip) path: their
+        // bytes are the signed samples already, no XOR; offset-binary input goes through the
+        // run-time-mode kernel
+        const uint32_t xormask = (MODE_T >= 0) ? 0u : a.xormask;
         const uint32_t esz = elem_bytes(mode);
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
         const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
@@ -835,6 +1198,14 @@ struct FftKernel {
         for (int i = 0; i < TAB_REGS; ++i) {
             const int e = tid + i * Cfg::WG;
             tabv[i] = a.tw_small[e < TAB_COPY ? e : TAB_COPY - 1];  // clamped, not predicated: no branch
+        }
+        // deferred middle-pass twiddles (OPT 128): row k = (C1 t + c) % Ns1 of the table, per column
+        constexpr int R1 = Cfg::R(1), C1 = Cfg::C(1), Ns1 = Cfg::Ns(1);
+        cf tw1[DEFER ? C1 * (R1 / 2) : 1];
+        if constexpr (DEFER) {
+            const int t1 = pass_lane<1>(t);
+#pragma unroll
+            for (int c = 0; c < C1; ++c) ld_c<R1 / 2>(a.tw_def + ((C1 * t1 + c) % Ns1) * (R1 / 2), tw1 + c * (R1 / 2));
         }
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
@@ -905,7 +1276,7 @@ struct FftKernel {
         }
 
         unsigned iter = 0;
-        if (a.trace != nullptr && tid == 0) a.trace[32 * b + 6] = wall_clock64();  // prologue done
+        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) a.trace[32 * b + 6] = wall_clock64();  // prologue done
         while (u < n_units) {
             // Next unit: the ticket requested one iteration ago has long arrived.  If the
             // pool it came from is exhausted, steal from the others (synchronous; this only
@@ -948,22 +1319,38 @@ struct FftKernel {
                 for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], xormask, C0 * t, v + r * C0);
             }
 #pragma unroll
-            for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0>(v + c);
+            for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0, MI>(v + c);
             if constexpr (LAZY_SYNC) lazy_sync();  // the previous frame's last read is complete everywhere
             lds_write<0>(lds, v, t);
             frame_sync();
-            if (a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
+            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
             size_t un = u + gridDim.x;
-            if constexpr (DYNAMIC) {
-                if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
-                const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
-                par ^= 1u;
-                un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+            if constexpr (TK_LATE) {
+                // the ticket word is read in front of pass 1's data (LDS returns in order) and only
+                // waited for once those reads are in flight
+                const unsigned tkv = tk[par];
+                middle_pass<1>(lds, lds_all, v, a, t, tw1, [&]() {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned nu = __builtin_amdgcn_readfirstlane(tkv);
+                    par ^= 1u;
+                    un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+                    load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff,
+                             raw);
+                });
+            } else {
+                if constexpr (DYNAMIC) {
+                    if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
+                    const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
+                    par ^= 1u;
+                    un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+                }
+                if constexpr ((Cfg::ABL & 64) == 0) {  // ABL 64 (measurement only): the first unit's bytes are reused
+                    load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
+                }
+                middle_pass<1>(lds, lds_all, v, a, t, tw1);
             }
-            load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
-            middle_pass<1>(lds, lds_all, v, a, t);
 
             // last pass
             lds_read<LAST>(lds, v, tl);
@@ -971,7 +1358,7 @@ struct FftKernel {
             if constexpr (!LAZY_SYNC) frame_sync();  // the buffer is free for the next frame's pass 0
             if constexpr (Cfg::TWR && TW_FUSE) {
 #pragma unroll
-                for (int c = 0; c < CL; ++c) dft_regs_tw<RL, CL, CL>(v + c, twl + c, PRESCALED ? SC : 1.0f);
+                for (int c = 0; c < CL; ++c) dft_regs_tw<RL, CL, CL, MI>(v + c, twl + c, PRESCALED ? SC : 1.0f);
             } else if constexpr (Cfg::TWR) {
                 if constexpr (PRESCALED) {
 #pragma unroll
@@ -990,11 +1377,11 @@ struct FftKernel {
             }
             if constexpr (!(Cfg::TWR && TW_FUSE)) {
 #pragma unroll
-                for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0>(v + c);
+                for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0, MI>(v + c);
             }
             epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, tl);
             u = un;
-            if (a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * b + 8 + iter] = wall_clock64();
+            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * b + 8 + iter] = wall_clock64();
             ++iter;
         }
 
@@ -1008,7 +1395,7 @@ struct FftKernel {
                 for (unsigned q = 0; q <= POOLS; ++q) a.ctr[32 * q] = 0;
             }
         }
-        if (a.trace != nullptr && tid == 0) {
+        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) {
             a.trace[32 * b + 1] = wall_clock64();
             a.trace[32 * b + 3] = __builtin_readcyclecounter();
         }

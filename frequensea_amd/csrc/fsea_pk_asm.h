@@ -38,6 +38,29 @@ __device__ __forceinline__ cf pk_cmul_add(cf a, cf w, cf c) {
     return t;
 }
 
+// a + (-i) b = (a.x + b.y, a.y - b.x) and a + i b = (a.x - b.y, a.y + b.x): the +-i butterflies as plain
+// packed adds (swizzle and one-lane negation in the modifiers; no multiplier involved).
+__device__ __forceinline__ cf pk_add_mi(cf a, cf b) {
+    cf t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ cf pk_add_pi(cf a, cf b) {
+    cf t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+
+// c + a * (-i w): the same product with the twiddle rotated by -i = W^{L/4}, (-i w) = (w.y, -w.x),
+// selected by modifiers alone, so that the deferred-twiddle butterflies (dft_regs_def) keep one
+// register pair per twiddle pair {w, -i w}.
+__device__ __forceinline__ cf pk_cmul_add_mi(cf a, cf w, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(c));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "+v"(t) : "v"(a), "v"(w));
+    return t;
+}
+
 // Diagnostics only (FSEA_TRACE): where a workgroup runs.
 __device__ __forceinline__ unsigned read_hw_id() {
     unsigned v;

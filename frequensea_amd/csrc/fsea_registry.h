@@ -1,4 +1,4 @@
-// fsea_registry.h -- table of compiled kernel variants (host side).
+// fsea_registry.h -- table of compiled kernel configurations (host side).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -8,83 +8,98 @@
 
 namespace fsea {
 
+// The __global__ entry points one configuration may have.  The three compile-time-mode kernels
+// serve raw int8 input (flip: the bytes are the signed samples, no XOR) with the epilogue fixed:
+// the nrf_fft_process path (MAG, src/nrf.c:619-630) and the sweep tools' pixel paths (DB5 with the
+// DC fix, c/fft-batch-broad.c:106-121; DB10, c/fft-batch.c:83-94).  K_U8 takes any epilogue and
+// either byte convention at run time (uniform branch), K_U8_ROT adds the fused frequency shift,
+// K_F32 takes f32-complex input (the NUT_BUFFER_F64 branch).
+enum : int { K_U8_MAG = 0, K_U8_DB5 = 1, K_U8_DB10 = 2, K_U8 = 3, K_U8_ROT = 4, K_F32 = 5, K_COUNT = 6 };
+
 struct KernelEntry {
     int n;                 // transform size
-    const char *variant;   // "" = default for this n
+    const char *variant;   // "" = the product configuration of this n
     int t, fpw, wg, np;
     int radix[4];
     size_t lds_bytes;
     int c0;                // samples per pass-0 load (hop must be a multiple)
-    const void *fn_u8_mag; // __global__ function addresses (occupancy queries)
-    const void *fn_u8;
-    const void *fn_f32;
-    const void *fn_u8_rot; // u8 input with the fused frequency shift
-    const char *name_u8_mag; // symbol names as rocprof shows them
-    const char *name_u8;
-    const char *name_f32;
-    const char *name_u8_rot;
-    void (*launch)(int in_kind, const FftArgs &args, unsigned grid, hipStream_t stream);
+    const void *fn[K_COUNT];    // __global__ function addresses (occupancy queries); null = not compiled
+    const char *name[K_COUNT];  // symbol names as rocprof shows them
+    void (*launch)(int kind, const FftArgs &args, unsigned grid, hipStream_t stream);
 };
 
 // Each k_*.hip translation unit exports `int fsea_kernels_<tag>(KernelEntry *out, int cap)`
-// which fills `out` with its variants and returns how many it has.
+// which fills `out` with its configurations and returns how many it has.
 
 }  // namespace fsea
 
-// Defines the __global__ entry points (u8 IQ: MAG / any mode / frequency-shifted; f32 complex) of one
-// configuration, with plain C names so that profiles are easy to read, and the
-// launch trampoline + KernelEntry for it.
-#define FSEA_DEFINE_KERNEL(NAME, VARIANT, ...)  /* NAME: C symbol stem; VARIANT: registry key */                                                        \
+#define FSEA_KERNEL_FN_(NAME, SUFFIX, ...)                                                            \
+    extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##SUFFIX(       \
+        fsea::FftArgs a) {                                                                            \
+        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                  \
+        fsea::FftKernel<NAME##_cfg, __VA_ARGS__>::run(a, lds);                                        \
+    }
+
+#define FSEA_KERNEL_ENTRY_HEAD_(NAME, VARIANT)                                                        \
+    NAME##_cfg::N, VARIANT, NAME##_cfg::T, NAME##_cfg::FPW, NAME##_cfg::WG, NAME##_cfg::NP,           \
+        {NAME##_cfg::R(0), NAME##_cfg::R(1), NAME##_cfg::R(2), NAME##_cfg::R(3)},                     \
+        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC, NAME##_cfg::C(0)
+
+// Defines the six __global__ entry points of one configuration, with plain C names so that
+// profiles are easy to read, and the launch trampoline + KernelEntry for it.
+#define FSEA_DEFINE_KERNEL(NAME, VARIANT, ...)  /* NAME: C symbol stem; VARIANT: registry key */     \
     using NAME##_cfg = fsea::FftCfg<__VA_ARGS__>;                                                     \
-    extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_u8(          \
-        fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
-        fsea::FftKernel<NAME##_cfg, fsea::IN_U8>::run(a, lds);                                        \
-    }                                                                                                 \
-    extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_u8_mag(      \
-        fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
-        fsea::FftKernel<NAME##_cfg, fsea::IN_U8, fsea::MODE_MAG>::run(a, lds);                        \
-    }                                                                                                 \
-    extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_f32(         \
-        fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
-        fsea::FftKernel<NAME##_cfg, fsea::IN_F32>::run(a, lds);                                       \
-    }                                                                                                 \
-    extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##_u8_rot(      \
-        fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                    \
-        fsea::FftKernel<NAME##_cfg, fsea::IN_U8, -1, true>::run(a, lds);                              \
-    }                                                                                                 \
-    static void NAME##_launch(int in_kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {    \
-        if (in_kind == fsea::IN_U8_ROT) {                                                             \
-            hipLaunchKernelGGL(NAME##_u8_rot, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);             \
-        } else if (in_kind == fsea::IN_U8 && a.mode == fsea::MODE_MAG && a.xormask == 0) {            \
-            hipLaunchKernelGGL(NAME##_u8_mag, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);             \
-        } else if (in_kind == fsea::IN_U8) {                                                          \
-            hipLaunchKernelGGL(NAME##_u8, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);                 \
-        } else {                                                                                      \
-            hipLaunchKernelGGL(NAME##_f32, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);                \
+    FSEA_KERNEL_FN_(NAME, _u8_mag, fsea::IN_U8, fsea::MODE_MAG)                                       \
+    FSEA_KERNEL_FN_(NAME, _u8_db5, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX)                              \
+    FSEA_KERNEL_FN_(NAME, _u8_db10, fsea::IN_U8, fsea::MODE_DB10_U8)                                  \
+    FSEA_KERNEL_FN_(NAME, _u8, fsea::IN_U8)                                                           \
+    FSEA_KERNEL_FN_(NAME, _u8_rot, fsea::IN_U8, -1, true)                                             \
+    FSEA_KERNEL_FN_(NAME, _f32, fsea::IN_F32)                                                         \
+    static void NAME##_launch(int kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {       \
+        const dim3 g(grid), b(NAME##_cfg::WG);                                                        \
+        switch (kind) {                                                                               \
+        case fsea::K_U8_MAG: hipLaunchKernelGGL(NAME##_u8_mag, g, b, 0, s, a); break;                 \
+        case fsea::K_U8_DB5: hipLaunchKernelGGL(NAME##_u8_db5, g, b, 0, s, a); break;                 \
+        case fsea::K_U8_DB10: hipLaunchKernelGGL(NAME##_u8_db10, g, b, 0, s, a); break;               \
+        case fsea::K_U8_ROT: hipLaunchKernelGGL(NAME##_u8_rot, g, b, 0, s, a); break;                 \
+        case fsea::K_F32: hipLaunchKernelGGL(NAME##_f32, g, b, 0, s, a); break;                       \
+        default: hipLaunchKernelGGL(NAME##_u8, g, b, 0, s, a); break;                                 \
         }                                                                                             \
     }                                                                                                 \
     static fsea::KernelEntry NAME##_entry() {                                                         \
         return fsea::KernelEntry{                                                                     \
-        NAME##_cfg::N,                                                                                \
-        VARIANT,                                                                                      \
-        NAME##_cfg::T,                                                                                \
-        NAME##_cfg::FPW,                                                                              \
-        NAME##_cfg::WG,                                                                               \
-        NAME##_cfg::NP,                                                                               \
-        {NAME##_cfg::R(0), NAME##_cfg::R(1), NAME##_cfg::R(2), NAME##_cfg::R(3)},                     \
-        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC,                                                       \
-        NAME##_cfg::C(0),                                                                             \
-        reinterpret_cast<const void *>(&NAME##_u8_mag),                                               \
-        reinterpret_cast<const void *>(&NAME##_u8),                                                   \
-        reinterpret_cast<const void *>(&NAME##_f32),                                                  \
-        reinterpret_cast<const void *>(&NAME##_u8_rot),                                               \
-        #NAME "_u8_mag",                                                                              \
-        #NAME "_u8",                                                                                  \
-        #NAME "_f32",                                                                                 \
-        #NAME "_u8_rot",                                                                              \
-        &NAME##_launch};                                                                              \
+            FSEA_KERNEL_ENTRY_HEAD_(NAME, VARIANT),                                                   \
+            {reinterpret_cast<const void *>(&NAME##_u8_mag), reinterpret_cast<const void *>(&NAME##_u8_db5), \
+             reinterpret_cast<const void *>(&NAME##_u8_db10), reinterpret_cast<const void *>(&NAME##_u8),    \
+             reinterpret_cast<const void *>(&NAME##_u8_rot), reinterpret_cast<const void *>(&NAME##_f32)},   \
+            {#NAME "_u8_mag", #NAME "_u8_db5", #NAME "_u8_db10", #NAME "_u8", #NAME "_u8_rot", #NAME "_f32"}, \
+            &NAME##_launch};                                                                          \
+    }
+
+// Tuning variants (libfsea_hip_tune.so only): the MAG kernel and the run-time-mode kernel; the
+// other kinds of such a plan fall back to the product configuration of the size.
+#define FSEA_DEFINE_KERNEL_LITE(NAME, VARIANT, ...)                                                   \
+    using NAME##_cfg = fsea::FftCfg<__VA_ARGS__>;                                                     \
+    FSEA_KERNEL_FN_(NAME, _u8_mag, fsea::IN_U8, fsea::MODE_MAG)                                       \
+    FSEA_KERNEL_FN_(NAME, _u8, fsea::IN_U8)                                                           \
+    static void NAME##_launch(int kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {       \
+        const dim3 g(grid), b(NAME##_cfg::WG);                                                        \
+        if (kind == fsea::K_U8_MAG) hipLaunchKernelGGL(NAME##_u8_mag, g, b, 0, s, a);                 \
+        else hipLaunchKernelGGL(NAME##_u8, g, b, 0, s, a);                                            \
+    }                                                                                                 \
+    static fsea::KernelEntry NAME##_entry() {                                                         \
+        return fsea::KernelEntry{                                                                     \
+            FSEA_KERNEL_ENTRY_HEAD_(NAME, VARIANT),                                                   \
+            {reinterpret_cast<const void *>(&NAME##_u8_mag), nullptr, nullptr,                        \
+             reinterpret_cast<const void *>(&NAME##_u8), nullptr, nullptr},                           \
+            {#NAME "_u8_mag", "", "", #NAME "_u8", "", ""},                                           \
+            &NAME##_launch};                                                                          \
+    }
+
+#define FSEA_REGISTER_BEGIN(TAG)                                                                      \
+    extern "C" int fsea_kernels_##TAG(fsea::KernelEntry *out, int cap) {                              \
+        int n = 0;
+#define FSEA_REGISTER(NAME) if (n < cap) out[n++] = NAME##_entry();
+#define FSEA_REGISTER_END                                                                             \
+        return n;                                                                                     \
     }

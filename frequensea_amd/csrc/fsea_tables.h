@@ -41,7 +41,7 @@ inline void build_twiddles(int np, const int *radix, std::vector<TwPair> &tw, si
     offsets[0] = 0;
     for (int i = 1; i < np - 1; ++i) pass_table(i);
     offsets[4] = tw.size();
-    for (long long h = 0; h < n / 64; ++h) {
+    for (long long h = 0; h < (n >= 64 ? n / 64 : 1); ++h) {
         const double ang = -two_pi * (double)(64 * h) / (double)n;
         tw.push_back(TwPair{(float)std::cos(ang), (float)std::sin(ang)});
     }
@@ -51,6 +51,26 @@ inline void build_twiddles(int np, const int *radix, std::vector<TwPair> &tw, si
     }
     pass_table(np - 1);
     for (int i = np; i < 4; ++i) offsets[i] = tw.size();
+}
+
+// Deferred-twiddle table of the V2 schedule's middle pass (dft_regs_def): lane group ka (the
+// pass-0 output digit, 0..ra-1) scales its pass-1 inputs x_b by om^b, om = W_{ra rb}^{ka}.  Row
+// ka holds rb/2 entries: for half = 1, 2, 4, ..: om^{rb/(2 half)} W_{2 half}^j, j < max(1, half/2),
+// i.e. exp(-2 pi i (ka + ra j) / (2 ra half)); angles reduced exactly in integers.
+inline void build_deferred_table(int ra, int rb, std::vector<TwPair> &out) {
+    const double two_pi = 6.283185307179586476925286766559;
+    out.clear();
+    for (int ka = 0; ka < ra; ++ka) {
+        for (int half = 1; half < rb; half <<= 1) {
+            const int distinct = half >= 2 ? half / 2 : 1;
+            const long long den = 2LL * ra * half;
+            for (int j = 0; j < distinct; ++j) {
+                const long long num = ((long long)ka + (long long)ra * j) % den;
+                const double ang = -two_pi * (double)num / (double)den;
+                out.push_back(TwPair{(float)std::cos(ang), (float)std::sin(ang)});
+            }
+        }
+    }
 }
 
 // Fused frequency shift (FftArgs::rot_row): the phasor between consecutive pass-0 rows of one

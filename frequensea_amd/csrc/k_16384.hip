@@ -1,9 +1,7 @@
-// N = 16384: 512 lanes x 32 points, 16 x 32 x 32, one workgroup per CU.
+// N = 16384: the product configuration (fsea_configs.h).
 #include "fsea_configs.h"
 #include "fsea_registry.h"
 FSEA_DEFINE_KERNEL(fsea_fft16384, "", FSEA_CFG_16384)
-extern "C" int fsea_kernels_16384(fsea::KernelEntry *out, int cap) {
-    int n = 0;
-    if (n < cap) out[n++] = fsea_fft16384_entry();
-    return n;
-}
+FSEA_REGISTER_BEGIN(16384)
+FSEA_REGISTER(fsea_fft16384)
+FSEA_REGISTER_END

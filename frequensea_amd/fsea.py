@@ -21,22 +21,44 @@ _MODE_DTYPE = {
 
 # Every symbol include/fsea.h declares; tests check the built library exports all of them.
 EXPORTS = [
-    "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_create_variant",
+    "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_reset",
     "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device",
     "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_exec_u8_shifted_device", "fsea_exec_u8_shifted_host", "fsea_mean_magnitude_u8_device",
     "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
-    "fsea_copy_to_host", "fsea_stream_synchronize", "fsea_time_exec_u8_device",
-    "fsea_plan_kernel_name", "fsea_last_error_string", "fsea_plan_read_trace",
+    "fsea_copy_to_host", "fsea_stream_synchronize",
+    "fsea_plan_kernel_name", "fsea_last_error_string",
+    "fsea_history_create", "fsea_history_destroy", "fsea_history_push_u8_host", "fsea_history_push_f64_host",
+    "fsea_history_shift", "fsea_history_get_f64",
 ]
+# include/fsea_tune.h: only libfsea_hip_tune.so (scripts/tune.py and friends) has these
+TUNE_EXPORTS = ["fsea_plan_create_variant", "fsea_time_exec_u8_device", "fsea_plan_read_trace"]
 
 
 class FseaError(RuntimeError):
     pass
 
 
+_USE_TUNE = False
+
+
+def use_tune_library():
+    """Measurement scripts call this first: load libfsea_hip_tune.so (a superset build with kernel
+    variants, ablations, traces and the timing helper) instead of the product library."""
+    global _USE_TUNE
+    if _LIB is not None and not _USE_TUNE:
+        raise FseaError("use_tune_library() must be called before the library is first used")
+    _USE_TUNE = True
+
+
+def tune_lib_path():
+    return os.path.join(_HERE, "libfsea_hip_tune.so")
+
+
 def lib_path():
-    # FSEA_HIP_LIB: tuning hook to load an alternative build of the same library
-    return os.environ.get("FSEA_HIP_LIB") or os.path.join(_HERE, "libfsea_hip.so")
+    # FSEA_HIP_LIB: load an alternative build of the same library
+    if os.environ.get("FSEA_HIP_LIB"):
+        return os.environ["FSEA_HIP_LIB"]
+    return tune_lib_path() if _USE_TUNE else os.path.join(_HERE, "libfsea_hip.so")
 
 
 def build(jobs=8):
@@ -60,7 +82,17 @@ def hip_lib():
         L.fsea_last_error_string.restype = ctypes.c_char_p
         L.fsea_device_count.argtypes = [ctypes.POINTER(ci)]
         L.fsea_plan_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci]
-        L.fsea_plan_create_variant.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.c_char_p]
+        L.fsea_plan_reset.argtypes = [vp]
+        L.fsea_history_create.argtypes = [vp, ci, ctypes.POINTER(vp)]
+        L.fsea_history_destroy.argtypes = [vp]
+        L.fsea_history_push_u8_host.argtypes = [vp, vp, ci]
+        L.fsea_history_push_f64_host.argtypes = [vp, vp]
+        L.fsea_history_shift.argtypes = [vp, ci]
+        L.fsea_history_get_f64.argtypes = [vp, vp]
+        if hasattr(L, "fsea_plan_create_variant"):     # the tuning library
+            L.fsea_plan_create_variant.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.c_char_p]
+            L.fsea_time_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp, ci, ctypes.POINTER(ctypes.c_float)]
+            L.fsea_plan_read_trace.argtypes = [vp, vp, ctypes.c_uint]
         L.fsea_plan_destroy.argtypes = [vp]
         L.fsea_plan_grid.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
                                      ctypes.POINTER(sz)]
@@ -82,7 +114,6 @@ def hip_lib():
         L.fsea_copy_to_device.argtypes = [ci, vp, vp, sz]
         L.fsea_copy_to_host.argtypes = [ci, vp, vp, sz]
         L.fsea_stream_synchronize.argtypes = [vp, vp]
-        L.fsea_time_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp, ci, ctypes.POINTER(ctypes.c_float)]
         _LIB = L
     return _LIB
 
@@ -108,8 +139,10 @@ class Plan:
         self.hop = fft_size if hop is None else hop
         self.mode = mode
         self.device = device
-        if variant is None:
+        if not variant:
             _check(self._L.fsea_plan_create(ctypes.byref(self._p), fft_size, self.hop, mode, device))
+        elif not hasattr(self._L, "fsea_plan_create_variant"):
+            raise FseaError("kernel variants live in libfsea_hip_tune.so: call fsea.use_tune_library() first")
         else:
             _check(self._L.fsea_plan_create_variant(ctypes.byref(self._p), fft_size, self.hop, mode, device,
                                                     variant.encode()))
@@ -150,7 +183,13 @@ class Plan:
         _check(self._L.fsea_exec_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_out_ptr,
                                            stream or None))
 
+    def reset(self):
+        _check(self._L.fsea_plan_reset(self._p))
+
     def time_device(self, d_iq_ptr, n_frames, d_out_ptr, reps, flip=True, stream=0):
+        """Tuning library only (fsea_time_exec_u8_device)."""
+        if not hasattr(self._L, "fsea_time_exec_u8_device"):
+            raise FseaError("the timing helper lives in libfsea_hip_tune.so: call fsea.use_tune_library() first")
         ms = ctypes.c_float(0)
         _check(self._L.fsea_time_exec_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_out_ptr,
                                                 stream or None, reps, ctypes.byref(ms)))

@@ -12,6 +12,13 @@
  * DC patch (one fused kernel).  What changed on the host: the history is a
  * ring (the reference memmoves the whole history, 8 MiB at 1024x1024, per
  * row: src/nrf.c:617), linearised only in nrf_fft_get_buffer.
+ *
+ * NRF_FFT_HISTORY=device in the environment keeps that ring in HBM instead
+ * (fsea_history_*, include/fsea.h): process writes the row in place on the
+ * device, shift is a kernel, get_buffer is one device-to-host transfer of H*N
+ * f32 plus one widening.  Same results bit for bit; which one is faster
+ * depends on how often get_buffer is called per process (profiles/,
+ * scripts/nrf_latency.py): the default is the host ring.
  */
 #include <math.h>
 #include <stdio.h>
@@ -49,10 +56,19 @@ nrf_fft *nrf_fft_new(int fft_size, int fft_history_size) {
     int rc = fsea_plan_create(&plan, fft_size, fft_size, FSEA_MODE_MAG_F32, dev_env ? atoi(dev_env) : 0);
     if (rc != FSEA_OK) fsea_fatal("fsea_plan_create", rc);
     fft->backend = plan;
-    fft->buffer = (double *)calloc((size_t)fft_size * (size_t)fft_history_size, sizeof(double));
+    const char *hist_env = getenv("NRF_FFT_HISTORY");
+    if (hist_env != NULL && strcmp(hist_env, "device") == 0) {
+        fsea_history *hist = NULL;
+        rc = fsea_history_create(plan, fft_history_size, &hist);
+        if (rc != FSEA_OK) fsea_fatal("fsea_history_create", rc);
+        fft->device_history = hist;
+    }
+    fft->buffer = fft->device_history != NULL
+                      ? NULL
+                      : (double *)calloc((size_t)fft_size * (size_t)fft_history_size, sizeof(double));
     fft->row_f32 = (float *)calloc((size_t)fft_size, sizeof(float));
     fft->scratch = calloc((size_t)fft_size * 2, sizeof(double));
-    if (fft->buffer == NULL || fft->row_f32 == NULL || fft->scratch == NULL) {
+    if ((fft->buffer == NULL && fft->device_history == NULL) || fft->row_f32 == NULL || fft->scratch == NULL) {
         fprintf(stderr, "NRF FFT fatal error: out of memory\n");
         exit(EXIT_FAILURE);
     }
@@ -66,7 +82,10 @@ void nrf_fft_shift(nrf_fft *fft, double d) {
     const int shift = (int)round(n / d);
     if (shift == 0) return;
     pthread_mutex_lock(&fft->mutex);
-    if (abs(shift) >= n) {
+    if (fft->device_history != NULL) {
+        const int rc = fsea_history_shift((fsea_history *)fft->device_history, shift);
+        if (rc != FSEA_OK) fsea_fatal("fsea_history_shift", rc);
+    } else if (abs(shift) >= n) {
         /* shifted out of range: start over */
         memset(fft->buffer, 0, sizeof(double) * (size_t)n * (size_t)fft->fft_history_size);
     } else {
@@ -105,7 +124,11 @@ void nrf_fft_process(nrf_fft *fft, nut_buffer *buffer) {
             iq = pad;
         }
         /* device buffers are already offset binary (src/nrf.c:103-106) -> flip = 0 */
-        rc = fsea_exec_u8_host(plan, iq, 1, 0, fft->row_f32);
+        if (fft->device_history != NULL) {
+            rc = fsea_history_push_u8_host((fsea_history *)fft->device_history, iq, 0);
+        } else {
+            rc = fsea_exec_u8_host(plan, iq, 1, 0, fft->row_f32);
+        }
         if (rc != FSEA_OK) fsea_fatal("fsea_exec_u8_host", rc);
     } else {
         const double *iq = buffer->data.f64;
@@ -115,13 +138,19 @@ void nrf_fft_process(nrf_fft *fft, nut_buffer *buffer) {
             memcpy(pad, buffer->data.f64, sizeof(double) * (size_t)have * 2);
             iq = pad;
         }
-        rc = fsea_exec_f64_host(plan, iq, 1, fft->row_f32);
+        if (fft->device_history != NULL) {
+            rc = fsea_history_push_f64_host((fsea_history *)fft->device_history, iq);
+        } else {
+            rc = fsea_exec_f64_host(plan, iq, 1, fft->row_f32);
+        }
         if (rc != FSEA_OK) fsea_fatal("fsea_exec_f64_host", rc);
     }
-    /* push as the newest row: the ring head moves back by one */
-    fft->ring_head = (fft->ring_head + fft->fft_history_size - 1) % fft->fft_history_size;
-    double *row = fft->buffer + (size_t)fft->ring_head * (size_t)n;
-    for (int i = 0; i < n; i++) row[i] = (double)fft->row_f32[i];
+    if (fft->device_history == NULL) {
+        /* push as the newest row: the ring head moves back by one */
+        fft->ring_head = (fft->ring_head + fft->fft_history_size - 1) % fft->fft_history_size;
+        double *row = fft->buffer + (size_t)fft->ring_head * (size_t)n;
+        for (int i = 0; i < n; i++) row[i] = (double)fft->row_f32[i];
+    }
     pthread_mutex_unlock(&fft->mutex);
 }
 
@@ -129,6 +158,12 @@ nut_buffer *nrf_fft_get_buffer(nrf_fft *fft) {
     const int n = fft->fft_size, h = fft->fft_history_size;
     nut_buffer *out = nut_private_new_f64_unfilled(n * h, 1); /* both memcpys below cover it entirely */
     pthread_mutex_lock(&fft->mutex);
+    if (fft->device_history != NULL) {
+        const int rc = fsea_history_get_f64((fsea_history *)fft->device_history, out->data.f64);
+        if (rc != FSEA_OK) fsea_fatal("fsea_history_get_f64", rc);
+        pthread_mutex_unlock(&fft->mutex);
+        return out;
+    }
     const int first = h - fft->ring_head; /* rows from the head to the end of storage */
     memcpy(out->data.f64, fft->buffer + (size_t)fft->ring_head * (size_t)n, sizeof(double) * (size_t)first * (size_t)n);
     memcpy(out->data.f64 + (size_t)first * (size_t)n, fft->buffer, sizeof(double) * (size_t)fft->ring_head * (size_t)n);
@@ -138,6 +173,7 @@ nut_buffer *nrf_fft_get_buffer(nrf_fft *fft) {
 
 void nrf_fft_free(nrf_fft *fft) {
     if (fft == NULL) return;
+    fsea_history_destroy((fsea_history *)fft->device_history);
     fsea_plan_destroy((fsea_plan *)fft->backend);
     pthread_mutex_destroy(&fft->mutex);
     free(fft->buffer);

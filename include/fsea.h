@@ -42,6 +42,7 @@ extern "C" {
 #endif
 
 typedef struct fsea_plan fsea_plan;
+typedef struct fsea_history fsea_history;
 
 /* Epilogue modes.  Output element type and row length are per mode. */
 enum {
@@ -70,18 +71,14 @@ enum {
 /* Number of visible HIP devices (0 and FSEA_ENODEVICE when there are none). */
 int fsea_device_count(int *count);
 
-/* fft_size: power of two, 128 <= fft_size <= 16384.
+/* fft_size: power of two, 32 <= fft_size <= 16384 (fftw_plan_dft_1d takes any size; the scripts and
+ * tools of the reference use powers of two, 128 ... 16384; other sizes fail with FSEA_EINVAL).
  * hop: samples between successive frame starts (hop == fft_size: back-to-back
  * frames as in c/fft-batch.c; hop < fft_size: overlapped STFT).  hop must be a
  * positive multiple of 8.
  * device: HIP device ordinal. */
 int fsea_plan_create(fsea_plan **plan, int fft_size, int hop, int mode, int device);
 int fsea_plan_destroy(fsea_plan *plan);
-
-/* Tuning hook: same as fsea_plan_create but selects a named kernel variant for
- * the size ("" = the default).  Unknown variants fail with FSEA_EINVAL. */
-int fsea_plan_create_variant(fsea_plan **plan, int fft_size, int hop, int mode, int device,
-                             const char *variant);
 
 /* Launch geometry the plan would use for n_frames (persistent grid, workgroup
  * size, static LDS bytes per workgroup).  Any out-pointer may be NULL. */
@@ -99,7 +96,10 @@ int fsea_plan_fft_size(const fsea_plan *plan);
  * d_out: device pointer, n_frames rows of fsea_plan_row_bytes().
  * stream: hipStream_t as void*; NULL is HIP's null (default) stream, which is
  * also what torch.cuda.current_stream().cuda_stream is unless a side stream
- * is current.  Asynchronous with respect to the host. */
+ * is current.  Asynchronous with respect to the host.
+ * A plan may be launched from several host threads and on up to 64 different streams; launches on
+ * one stream run in order, launches on different streams may overlap.  The calls leave the
+ * caller's current HIP device unchanged. */
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
                         void *d_out, void *stream);
 
@@ -125,6 +125,21 @@ int fsea_exec_u8_shifted_host(fsea_plan *plan, const uint8_t *iq, size_t n_frame
 
 /* F64 interleaved complex input (src/nrf.c:607-609: no /256, no flip). */
 int fsea_exec_f64_host(fsea_plan *plan, const double *iq, size_t n_frames, void *out);
+
+/* Device-resident history of MAG_F32 rows, newest first: nrf_fft's `buffer` (src/nrf.h:133,
+ * src/nrf.c:565, 616-617) kept in HBM as a ring.  push = one nrf_fft_process: the kernel writes the
+ * new row straight into the ring (the reference memmoves the whole history by one row first);
+ * shift = nrf_fft_shift's per-row scroll for an integer number of bins (src/nrf.c:569-596: > 0 moves
+ * rows left, < 0 right, vacated bins zero, |shift| >= fft_size clears the history), as a kernel;
+ * get = nrf_fft_get_buffer: ONE device-to-host transfer of rows * fft_size f32 and one widening to
+ * f64 into `out` (rows * fft_size doubles).  The plan must be a MAG_F32 plan and must outlive the
+ * history.  All calls are synchronous. */
+int fsea_history_create(fsea_plan *plan, int rows, fsea_history **history);
+int fsea_history_destroy(fsea_history *history);
+int fsea_history_push_u8_host(fsea_history *history, const uint8_t *iq, int flip);
+int fsea_history_push_f64_host(fsea_history *history, const double *iq);
+int fsea_history_shift(fsea_history *history, int shift);
+int fsea_history_get_f64(fsea_history *history, double *out);
 
 /* Mean of sqrt(re^2+im^2) over the first n_frames rows of a device-resident
  * u8 IQ block (c/fft-batch-broad.c:81-98).  Synchronous. */
@@ -154,22 +169,15 @@ int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes);
 /* Waits for `stream` (NULL = the null stream) on the plan's device. */
 int fsea_stream_synchronize(fsea_plan *plan, void *stream);
 
-/* Measurement helper: runs fsea_exec_u8_device `reps` times back to back on
- * `stream` between two HIP events recorded on that same stream and returns the
- * average milliseconds per launch. */
-int fsea_time_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
-                             int flip, void *d_out, void *stream, int reps,
-                             float *avg_ms);
+/* Recovery after an aborted launch (device fault, killed context): waits for the device and
+ * re-zeroes the plan's internal frame-distribution counters.  Not needed in normal operation. */
+int fsea_plan_reset(fsea_plan *plan);
 
-/* Diagnostics: when the environment variable FSEA_TRACE is set at plan creation, every launch
- * records per workgroup {wall-clock start, end (100 MHz ticks), shader-clock start, end, HW_ID,
- * XCC_ID, 0, 0, end of iteration 0..23}; this copies the [n_workgroups][32] words of the last
- * launch (scripts/wg_trace.py). */
-int fsea_plan_read_trace(fsea_plan *plan, unsigned long long *out, unsigned n_workgroups);
-
-/* Name of the kernel the plan launches (for matching rocprof rows).  MAG_F32 plans name the
- * compile-time kernel `*_u8_mag`, which serves flip != 0 (raw int8 input); with flip == 0 the same
- * plan launches the run-time-mode kernel `*_u8`. */
+/* Name of the kernel the plan launches for raw int8 input (flip != 0), for matching rocprof rows:
+ * MAG_F32, DB5_U8_DCFIX and DB10_U8 plans have compile-time kernels (`*_u8_mag`, `*_u8_db5`,
+ * `*_u8_db10`); the other modes, and any mode with flip == 0, run the run-time-mode kernel `*_u8`.
+ * Kernel variants, per-workgroup traces and the timing helper live in the separate tuning
+ * library (include/fsea_tune.h, libfsea_hip_tune.so); this library has one kernel set per size. */
 const char *fsea_plan_kernel_name(const fsea_plan *plan);
 
 const char *fsea_last_error_string(void);

@@ -131,6 +131,7 @@ typedef struct {
     float *row_f32;        /* staging for one device row */
     void *scratch;         /* zero-padded / converted input for short buffers */
     pthread_mutex_t mutex;
+    void *device_history;  /* fsea_history* when NRF_FFT_HISTORY=device: the ring lives in HBM, `buffer` is NULL */
 } nrf_fft;
 
 /* Plan + zeroed history of fft_history_size rows.  Exits if no GPU. */

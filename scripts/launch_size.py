@@ -5,6 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from frequensea_amd import fsea
+fsea.use_tune_library()
 
 def dev_alloc(nbytes):
     p = ctypes.c_void_p()

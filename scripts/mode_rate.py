@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from frequensea_amd import fsea  # noqa: E402
+fsea.use_tune_library()
 
 TOTAL_SAMPLES = 1 << 27
 NAMES = {0: "MAG_F32", 1: "DB10_U8", 2: "DB5_U8_DCFIX", 3: "COMPLEX_F32", 4: "MAG_NODC_F32", 5: "DB_F32"}

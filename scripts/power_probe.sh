@@ -10,6 +10,7 @@ import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from frequensea_amd import fsea
+fsea.use_tune_library()
 L = fsea.hip_lib()
 n, total = 8192, 1 << 27
 host = np.random.default_rng(1).integers(-70, 70, 2 * total, dtype=np.int8).view(np.uint8)

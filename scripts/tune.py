@@ -11,13 +11,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from frequensea_amd import fsea  # noqa: E402
+fsea.use_tune_library()
 
 VARIANTS = {
-    8192: ["", "x0", "x7", "A", "B", "D", "notwl", "notwr",
-           "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu"],
-    1024: ["", "x0", "B", "C", "D"],
-    4096: ["", "x0", "B", "C", "D"],
-    128: [""], 256: [""], 512: [""], 2048: ["", "x0", "B", "C"], 16384: ["", "B"],
+    8192: ["", "r1", "nd", "x0", "x7", "tk", "pr", "v2", "v2s", "A", "B", "D", "notwl", "notwr",
+           "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu", "abl_noload", "abl_nomag",
+           "abl_v2l", "abl_v2sl", "abl_v2na"],
+    1024: ["", "r1", "x0", "B", "C", "D"],
+    4096: ["", "x0", "df", "B", "C", "D"],
+    32: [""], 64: [""], 128: [""], 256: [""], 512: [""], 2048: ["", "x0", "df", "B", "C"],
+    16384: ["", "r1", "nd", "B"],
 }
 TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch
 ROUNDS = 7

@@ -6,6 +6,7 @@ os.environ["FSEA_TRACE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from frequensea_amd import fsea
+fsea.use_tune_library()
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
@@ -19,7 +20,7 @@ d_out = [dev_alloc(4 * n * frames) for _ in range(sets)]
 host = np.random.default_rng(1).integers(-70, 70, 2 * n * frames, dtype=np.int8).view(np.uint8)
 for d in d_in:
     fsea._check(L.fsea_copy_to_device(0, d, host.ctypes.data, host.nbytes))
-plan = fsea.Plan(n)
+plan = fsea.Plan(n, variant=os.environ.get("FSEA_VARIANT"))
 grid = plan.grid(frames)[0]
 for k in range(200):                      # warm clocks, rotate buffers
     plan.exec_device(d_in[k % sets], frames, d_out[k % sets])

@@ -10,7 +10,7 @@
 #include <thread>
 #include <vector>
 
-#include "fsea_configs.h"
+#include "fsea_configs_tune.h"
 #include "fsea_fft_core.h"
 #include "fsea_tables.h"
 
@@ -41,6 +41,15 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
     fsea::build_twiddles(Cfg::NP, radix, tw, off);
     for (int i = 0; i < 4; ++i) a.tw[i] = reinterpret_cast<const fsea::cf *>(tw.data()) + off[i];
     a.tw_small = reinterpret_cast<const fsea::cf *>(tw.data());
+    std::vector<fsea::TwPair> twd;
+    fsea::build_deferred_table(Cfg::R(0), Cfg::R(1), twd);
+    twd.resize(twd.size() + 2);  // 16-byte alignment slack
+    const fsea::TwPair *twd_p = twd.data();
+    if (reinterpret_cast<uintptr_t>(twd_p) & 15) {
+        std::memmove(twd.data() + 1, twd.data(), (twd.size() - 2) * sizeof(fsea::TwPair));
+        twd_p = twd.data() + 1;
+    }
+    a.tw_def = reinterpret_cast<const fsea::cf *>(twd_p);
     std::vector<unsigned> ctr(9 * 32, 0u);
     a.ctr = ctr.data();
     for (unsigned b = 0; b < grid; ++b) {
@@ -78,7 +87,9 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
 template <class Cfg>
 static int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsigned grid) {
     if (in_kind == fsea::IN_U8_ROT) run_grid<Cfg, fsea::IN_U8, -1, true>(a, grid);
-    else if (in_kind == fsea::IN_U8 && mode_t == 0) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
+    else if (in_kind == fsea::IN_U8 && mode_t == fsea::MODE_MAG) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
+    else if (in_kind == fsea::IN_U8 && mode_t == fsea::MODE_DB5_U8_DCFIX) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX>(a, grid);
+    else if (in_kind == fsea::IN_U8 && mode_t == fsea::MODE_DB10_U8) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB10_U8>(a, grid);
     else if (in_kind == fsea::IN_U8) run_grid<Cfg, fsea::IN_U8, -1>(a, grid);
     else run_grid<Cfg, fsea::IN_F32, -1>(a, grid);
     return 0;
@@ -114,33 +125,48 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
     a.trace = nullptr;
-    const int mt = (specialised && mode == fsea::MODE_MAG && in_kind == fsea::IN_U8 && flip) ? 0 : -1;
+    // the compile-time-mode kernels (MAG, DB5, DB10) serve raw int8 input (flip)
+    const bool has_fixed = mode == fsea::MODE_MAG || mode == fsea::MODE_DB5_U8_DCFIX || mode == fsea::MODE_DB10_U8;
+    const int mt = (specialised && has_fixed && in_kind == fsea::IN_U8 && flip) ? mode : -1;
     const std::string v = variant ? variant : "";
     if (!v.empty()) {
 #define EMU_VARIANT(NN, NAME, CFG) \
     if (n == NN && v == NAME) return dispatch<fsea::FftCfg<CFG>>(in_kind, mt, a, grid);
+        EMU_VARIANT(8192, "r1", FSEA_CFG_8192_R1)
+        EMU_VARIANT(8192, "nd", FSEA_CFG_8192_ND)
+        EMU_VARIANT(8192, "v2", FSEA_CFG_8192_V2)
+        EMU_VARIANT(8192, "v2s", FSEA_CFG_8192_V2S)
+        EMU_VARIANT(8192, "tk", FSEA_CFG_8192_TK)
+        EMU_VARIANT(8192, "pr", FSEA_CFG_8192_PR)
         EMU_VARIANT(8192, "x0", FSEA_CFG_8192_X0)
         EMU_VARIANT(8192, "x7", FSEA_CFG_8192_X7)
-        EMU_VARIANT(4096, "x0", FSEA_CFG_4096_X0)
-        EMU_VARIANT(2048, "x0", FSEA_CFG_2048_X0)
-        EMU_VARIANT(1024, "x0", FSEA_CFG_1024_X0)
         EMU_VARIANT(8192, "A", FSEA_CFG_8192_A)
         EMU_VARIANT(8192, "B", FSEA_CFG_8192_B)
         EMU_VARIANT(8192, "D", FSEA_CFG_8192_D)
         EMU_VARIANT(8192, "notwl", FSEA_CFG_8192_NOTWL)
         EMU_VARIANT(8192, "notwr", FSEA_CFG_8192_NOTWR)
-        EMU_VARIANT(1024, "B", FSEA_CFG_1024_B)
-        EMU_VARIANT(1024, "C", FSEA_CFG_1024_C)
-        EMU_VARIANT(1024, "D", FSEA_CFG_1024_D)
+        EMU_VARIANT(4096, "x0", FSEA_CFG_4096_X0)
+        EMU_VARIANT(4096, "df", FSEA_CFG_4096_DF)
         EMU_VARIANT(4096, "B", FSEA_CFG_4096_B)
         EMU_VARIANT(4096, "C", FSEA_CFG_4096_C)
         EMU_VARIANT(4096, "D", FSEA_CFG_4096_D)
-        EMU_VARIANT(16384, "B", FSEA_CFG_16384_B)
+        EMU_VARIANT(2048, "x0", FSEA_CFG_2048_X0)
+        EMU_VARIANT(2048, "df", FSEA_CFG_2048_DF)
         EMU_VARIANT(2048, "B", FSEA_CFG_2048_B)
         EMU_VARIANT(2048, "C", FSEA_CFG_2048_C)
+        EMU_VARIANT(1024, "r1", FSEA_CFG_1024_R1)
+        EMU_VARIANT(1024, "x0", FSEA_CFG_1024_X0)
+        EMU_VARIANT(1024, "B", FSEA_CFG_1024_B)
+        EMU_VARIANT(1024, "C", FSEA_CFG_1024_C)
+        EMU_VARIANT(1024, "D", FSEA_CFG_1024_D)
+        EMU_VARIANT(16384, "r1", FSEA_CFG_16384_R1)
+        EMU_VARIANT(16384, "nd", FSEA_CFG_16384_ND)
+        EMU_VARIANT(16384, "B", FSEA_CFG_16384_B)
         return -2;
     }
     switch (n) {
+    case 32: return dispatch<fsea::FftCfg<FSEA_CFG_32>>(in_kind, mt, a, grid);
+    case 64: return dispatch<fsea::FftCfg<FSEA_CFG_64>>(in_kind, mt, a, grid);
     case 128: return dispatch<fsea::FftCfg<FSEA_CFG_128>>(in_kind, mt, a, grid);
     case 256: return dispatch<fsea::FftCfg<FSEA_CFG_256>>(in_kind, mt, a, grid);
     case 512: return dispatch<fsea::FftCfg<FSEA_CFG_512>>(in_kind, mt, a, grid);

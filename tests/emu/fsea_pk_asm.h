@@ -21,6 +21,15 @@ static inline cf pk_cmul_add(cf a, cf w, cf c) {
     return t;
 }
 
+static inline cf pk_add_mi(cf a, cf b) { return cf{a[0] + b[1], a[1] - b[0]}; }
+static inline cf pk_add_pi(cf a, cf b) { return cf{a[0] - b[1], a[1] + b[0]}; }
+
+static inline cf pk_cmul_add_mi(cf a, cf w, cf c) {
+    cf t = cf{fmaf(a[0], w[1], c[0]), fmaf(a[1], w[1], c[1])};
+    t = cf{fmaf(a[1], w[0], t[0]), fmaf(-a[0], w[0], t[1])};
+    return t;
+}
+
 static inline unsigned read_hw_id() { return 0; }
 static inline unsigned read_xcc_id() { return 0; }
 

@@ -92,6 +92,7 @@ static inline void emu_bs128(emu_u32x4 d, emu_rsrc rs, uint32_t v, uint32_t s, i
 static inline unsigned long long wall_clock64() { return 0; }
 #define __builtin_readcyclecounter() 0ull
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
 static inline void sincospi(double x, double *s, double *c) {
     *s = sin(3.14159265358979323846 * x);

@@ -20,7 +20,7 @@ def emu_lib():
         out = os.path.join(ROOT, "tests", "emu", "libfsea_emu.so")
         csrc = os.path.join(ROOT, "frequensea_amd", "csrc")
         deps = [src, os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")] + [
-            os.path.join(csrc, f) for f in ("fsea_fft_core.h", "fsea_configs.h", "fsea_tables.h")] + [
+            os.path.join(csrc, f) for f in ("fsea_fft_core.h", "fsea_configs.h", "fsea_configs_tune.h", "fsea_tables.h")] + [
             os.path.join(ROOT, "tests", "emu", "fsea_pk_asm.h")]
         def stale():
             return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)

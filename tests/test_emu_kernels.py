@@ -10,7 +10,7 @@ from tests import parity
 from tests.conftest import GOLDEN_KEYS, synth_iq
 from tests.emu_util import emu_rows
 
-SIZES = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
 
 
 def frames_for(n):
@@ -26,7 +26,19 @@ def test_mag_all_sizes(n):
     assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])      # DC patch
 
 
-@pytest.mark.parametrize("n", [128, 1024, 4096, 8192])
+@pytest.mark.parametrize("n", [32, 256, 1024, 4096, 8192, 16384])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_compile_time_pixel_kernels(n, mode):
+    """`*_u8_db10` / `*_u8_db5`: epilogue and byte convention fixed at compile time (the sweep tools' path)."""
+    nf = 9 if n <= 1024 else 3
+    iq = synth_iq(300 + n + mode, 2 * nf * n)
+    got = emu_rows(iq, n, nf, mode=mode, grid=2, specialised=True)
+    parity.check_mode(got, iq, n, nf, n, True, mode)
+    if mode == 2:
+        assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
+
+
+@pytest.mark.parametrize("n", [32, 64, 128, 1024, 4096, 8192])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 def test_all_modes_runtime_dispatch(n, mode):
     nf = 9 if n <= 1024 else 3
@@ -101,12 +113,14 @@ def test_edge_inputs():
     assert emu_rows(z, n, 0).shape == (0, n)
 
 
-@pytest.mark.parametrize("n,variant", [(8192, "x0"), (8192, "x7"), (4096, "x0"), (2048, "x0"), (1024, "x0"), (8192, "A"), (8192, "B"), (8192, "D"),
-                                       (8192, "notwl"), (8192, "notwr"), (1024, "B"), (1024, "C"), (1024, "D"),
-                                       (4096, "B"), (4096, "C"), (4096, "D"), (16384, "B"), (2048, "B"),
-                                       (2048, "C")])
+@pytest.mark.parametrize("n,variant", [(8192, "r1"), (8192, "nd"), (8192, "v2"), (8192, "v2s"), (8192, "tk"), (8192, "pr"),
+                                       (8192, "x0"), (8192, "x7"), (8192, "A"), (8192, "B"), (8192, "D"),
+                                       (8192, "notwl"), (8192, "notwr"), (4096, "x0"), (4096, "df"), (4096, "B"),
+                                       (4096, "C"), (4096, "D"), (2048, "x0"), (2048, "df"), (2048, "B"), (2048, "C"),
+                                       (1024, "r1"), (1024, "x0"), (1024, "B"), (1024, "C"), (1024, "D"),
+                                       (16384, "r1"), (16384, "nd"), (16384, "B")])
 def test_tuning_variants(n, variant):
-    """Every kernel variant compiled into libfsea_hip.so (fsea_plan_create_variant) stays correct."""
+    """Every kernel variant compiled into libfsea_hip_tune.so (fsea_plan_create_variant) stays correct."""
     nf = 9 if n <= 1024 else 3
     iq = synth_iq(n + len(variant), 2 * nf * n)
     for mode in (0, 1, 3):
@@ -119,7 +133,7 @@ def test_random_geometry_sweep():
     (hop > N) and tiny hops, ragged frame counts, every epilogue."""
     rng = np.random.default_rng(2026)
     for _ in range(28):
-        n = int(rng.choice([128, 256, 512, 1024, 2048, 4096, 8192]))
+        n = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]))
         hop = int(rng.choice([8, 16, n // 4, n // 2, n, n + 8, 2 * n]))
         nf = int(rng.integers(1, 40 if n <= 1024 else 7))
         mode = int(rng.integers(0, 6))

@@ -3,6 +3,7 @@ reference-shaped nrf_fft API of libfsea_nrf.so, against the f64 oracle, the comm
 vectors from the reference's recorded captures, and -- at BASELINE.json's full sizes -- through
 size-independent properties (Parseval, tone position, sampled rows).  Tolerances: tests/parity.py."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -10,11 +11,11 @@ import pytest
 from frequensea_amd import fsea, nrf
 from oracle import oracle as O
 from tests import parity
-from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, synth_iq
+from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, ROOT, synth_iq
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
 
 
 class DeviceBuffer:
@@ -49,6 +50,18 @@ def test_device_present_and_library_loaded():
     p.close()
 
 
+def test_committed_traffic_figure_belongs_to_the_current_kernel():
+    """bench.py quotes roofline.traffic from profiles/traffic.json, a PMC measurement made once per round.
+    It goes stale when the default kernel changes: kernel name, grid, workgroup size and LDS bytes of the
+    headline plan must still be the ones it was measured on."""
+    import json
+    tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    p = fsea.Plan(8192)
+    assert tr["kernel"] == p.kernel_name
+    assert tr["grid_block_lds"] == list(p.grid(tr["frames"])), "re-run scripts/pmc.sh and update profiles/traffic.json"
+    p.close()
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_mag_rows_all_sizes(n):
     nf = 300 if n <= 1024 else 37
@@ -60,7 +73,7 @@ def test_mag_rows_all_sizes(n):
     plan.close()
 
 
-@pytest.mark.parametrize("n", [128, 1024, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [32, 64, 128, 1024, 4096, 8192, 16384])
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 def test_other_modes(n, mode):
     nf = 33
@@ -103,13 +116,20 @@ def test_random_geometry_sweep_on_gpu():
         plan.close()
 
 
-def test_flip_is_bit_exact_identity():
-    """flip=1 on raw int8 bytes and flip=0 on the same bytes ^ 0x80 must give identical bits."""
+def test_flip_matches_the_reference_byte_flip():
+    """a1 (src/nrf.c:100-109): (b + 128) % 256 on every byte.  The oracle's flip is that loop; the kernel
+    folds it into the conversion.  All 256 byte values in both components, against the oracle with
+    flip (raw int8) and without (bytes flipped by the oracle first), and the two GPU paths bit for bit."""
     n, nf = 1024, 64
     raw = synth_iq(5, 2 * nf * n)
+    raw[:512] = np.repeat(np.arange(256, dtype=np.uint8), 2)             # every byte value as I and as Q
+    flipped = O.flip_u8(raw)
+    assert np.array_equal(flipped, ((raw.astype(np.int32) + 128) % 256).astype(np.uint8))
     plan = fsea.Plan(n, mode=fsea.MODE_COMPLEX_F32)
     a = plan.exec_host(raw, nf, flip=True)
-    b = plan.exec_host(raw ^ np.uint8(0x80), nf, flip=False)
+    b = plan.exec_host(flipped, nf, flip=False)
+    parity.check_mode(a, raw, n, nf, n, True, 3)
+    parity.check_mode(b, flipped, n, nf, n, False, 3)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     plan.close()
 
@@ -136,6 +156,23 @@ def test_survey_known_answers_on_gpu(golden):
     assert abs(float(row.astype(np.float64).sum()) - 1567.312172) < 1e-2
     row = fsea.Plan(8192).exec_host(raw, 1)[0]
     assert row.argmax() == 3358 and abs(float(row.max()) - 162.437851) < 5e-4
+
+
+@pytest.mark.parametrize("n", [32, 256, 1024, 4096, 8192, 16384])
+def test_compile_time_pixel_kernels(n):
+    """The sweep tools' modes on raw int8 input run `*_u8_db5` / `*_u8_db10` (epilogue and byte
+    convention fixed at compile time); offset-binary input of the same plan runs `*_u8`.  Both
+    against the oracle's pixel rules (c/fft-batch.c:83-94, c/fft-batch-broad.c:106-121)."""
+    nf = 257 if n <= 1024 else 29
+    iq = synth_iq(40 + n, 2 * nf * n)
+    for mode, suffix in ((fsea.MODE_DB5_U8_DCFIX, "_u8_db5"), (fsea.MODE_DB10_U8, "_u8_db10")):
+        plan = fsea.Plan(n, mode=mode)
+        assert plan.kernel_name == "fsea_fft%d%s" % (n, suffix)
+        got = plan.exec_host(iq, nf, flip=True)
+        parity.check_mode(got, iq, n, nf, n, True, mode)
+        got2 = plan.exec_host(iq ^ np.uint8(0x80), nf, flip=False)      # run-time-mode kernel, same pixels
+        assert np.array_equal(got, got2)
+        plan.close()
 
 
 def test_device_resident_and_ragged_counts():
@@ -224,6 +261,60 @@ def test_concurrent_launches_of_one_plan_on_two_streams():
         d_out[k].free()
     for st in streams:
         hip.hipStreamDestroy(st)
+    plan.close()
+
+
+def test_many_overlapping_launches_on_four_streams_and_reset():
+    """One ticket-counter slot per stream (launches on a stream run in order; streams never share a
+    slot): far more than 64 launches in flight over four streams, multi-wave size, every launch
+    checked.  Then fsea_plan_reset, and the plan still works on a fifth stream."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    streams = [ctypes.c_void_p() for _ in range(5)]
+    for st in streams:
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0          # hipStreamNonBlocking
+    n, nf, reps = 4096, 300, 48                                               # 4 x 48 = 192 launches queued
+    plan = fsea.Plan(n)
+    iq = synth_iq(123, 2 * nf * n)
+    want = O.rows(iq, nf, n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    outs = [[DeviceBuffer(nf * n * 4) for _ in range(reps)] for _ in range(4)]
+    for r in range(reps):
+        for k in range(4):
+            plan.exec_device(d_in.ptr, nf - (r % 3), outs[k][r].ptr, stream=streams[k].value)
+    for st in streams[:4]:
+        assert hip.hipStreamSynchronize(st) == 0
+    for k in range(4):
+        for r in range(reps):
+            rows = nf - (r % 3)
+            got = outs[k][r].download(np.float32, (rows, n))
+            parity.check_float(got, want[:rows])
+            outs[k][r].free()
+    plan.reset()
+    d_out = DeviceBuffer(nf * n * 4)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr, stream=streams[4].value)
+    assert hip.hipStreamSynchronize(streams[4]) == 0
+    parity.check_float(d_out.download(np.float32, (nf, n)), want)
+    d_in.free()
+    d_out.free()
+    for st in streams:
+        hip.hipStreamDestroy(st)
+    plan.close()
+
+
+def test_calls_leave_the_current_device_alone():
+    """Every entry point runs on the plan's device and restores the caller's current HIP device
+    (ADVICE r01); with one GPU the observable part is that it stays 0 and nothing fails."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    dev = ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(dev)) == 0
+    before = dev.value
+    plan = fsea.Plan(256)
+    iq = synth_iq(9, 2 * 4 * 256)
+    plan.exec_host(iq, 4)
+    assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == before
     plan.close()
 
 

@@ -29,6 +29,23 @@ def test_fsea_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_tuning_library_is_a_superset_and_the_product_has_no_variants():
+    """include/fsea_tune.h lives in libfsea_hip_tune.so only: the product library registers one kernel
+    set per size and exports no variant / trace / timing entry point."""
+    import subprocess
+    tune = ctypes.CDLL(fsea.tune_lib_path())
+    names = declared_functions("fsea_tune.h")
+    assert names == set(fsea.TUNE_EXPORTS)
+    for name in names | set(fsea.EXPORTS):
+        assert hasattr(tune, name), name
+    prod = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(os.path.dirname(fsea.tune_lib_path()),
+                                                                                "libfsea_hip.so")]).decode()
+    for forbidden in ("fsea_abl", "variant", "read_trace", "time_exec", "8192v2", "8192r1"):
+        assert forbidden not in prod, forbidden
+    tuned = subprocess.check_output(["nm", "-D", "--defined-only", fsea.tune_lib_path()]).decode()
+    assert "fsea_abl8192_io_u8_mag" in tuned and "fsea_fft8192v2_u8_mag" in tuned
+
+
 def test_nrf_exports_every_declared_symbol():
     L = ctypes.CDLL(nrf.lib_path())
     for header, listed in (("nut.h", nrf.NUT_EXPORTS), ("nrf.h", nrf.NRF_EXPORTS)):
