@@ -170,8 +170,12 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
 def run_broad(args, rank, world, dist, torch, steps, warmup):
     """the fft-batch-broad sweep -- 512 centre frequencies x 256 frames x 4096-pt,
     u8 dB tiles (DB5 + DC fix), centre frequencies sharded over the ranks, tiles gathered to rank 0 over
-    RCCL and max-composited into the stitched image (c/fft-stitch-broad.c).  Strong scaling: the sweep
-    is fixed, a step is the whole sweep including gather and stitch."""
+    RCCL chunk by chunk (overlapped with the next chunk's FFT) and max-composited into the stitched image
+    (c/fft-stitch-broad.c).  Strong scaling: the sweep is fixed, a step is the whole sweep including gather
+    and stitch.  Two regimes, named in config.regime:
+      resident  the captures are in HBM when the step starts (gather-to-one-root is then link-bound);
+      ingest    the captures start in pinned host memory and every rank copies its shard over its own PCIe
+                link inside the step, chunk by chunk on a copy stream ahead of the FFT."""
     from frequensea_amd import fsea, sweep
 
     n, rows, tiles = 4096, 256, 512
@@ -180,18 +184,34 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
     plan = fsea.Plan(n, hop=n, mode=fsea.MODE_DB5_U8_DCFIX, device=dev.index)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4000000 + lo)
+    tile_bytes = 2 * rows * n
     samples = (hi - lo) * rows * n
     iq = torch.empty(2 * samples, dtype=torch.int8, device=dev)
     chunk = 1 << 24
     for s0 in range(0, 2 * samples, chunk):                     # int8 Gaussian sigma=20, generated on device
         e0 = min(2 * samples, s0 + chunk)
         iq[s0:e0] = torch.clamp(torch.round(torch.randn(e0 - s0, generator=gen, device=dev) * 20.0), -128, 127).to(torch.int8)
+    ingest = args.regime == "ingest"
+    host_iq = None
+    if ingest:
+        host_iq = torch.empty(2 * samples, dtype=torch.int8, pin_memory=True)
+        host_iq.copy_(iq)
+        iq.zero_()                                              # every step has to bring the bytes in again
     px = torch.empty((hi - lo, rows, n), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    compute = torch.cuda.current_stream()
+    copy_stream = torch.cuda.Stream() if ingest else None
+    stream = compute.cuda_stream
 
-    def make_tiles(a, b):
-        plan.exec_device(iq.data_ptr(), (b - a) * rows, px.data_ptr(), flip=True, stream=stream)   # one launch
-        return px
+    def make_tiles(a, b):                                       # tiles a..b-1 of the sweep, one launch
+        s0, s1 = (a - lo) * tile_bytes, (b - lo) * tile_bytes
+        if ingest:
+            with torch.cuda.stream(copy_stream):
+                iq[s0:s1].copy_(host_iq[s0:s1], non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record()
+            compute.wait_event(ready)
+        plan.exec_device(iq.data_ptr() + s0, (b - a) * rows, px.data_ptr() + (a - lo) * rows * n, flip=True, stream=stream)
+        return px[a - lo: b - lo]
 
     def composite(image, tile, x):
         fsea.composite_max_device(image.data_ptr(), tile.data_ptr(), x, 0, n, rows, image.shape[1], n,
@@ -201,9 +221,12 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         fsea.stitch_tiles_device(image.data_ptr(), stack.data_ptr(), count, first_x, n, n, rows, image.shape[1],
                                  device=dev.index, stream=stream)
 
+    # chunks exist to overlap the gather (and the H2D ingest) with the FFT; one GPU with resident input has neither
+    n_chunks = args.chunks if (world > 1 or ingest) else 1
+
     def step():
         return sweep.run_sweep(tiles, (rows, n), make_tiles, composite, dist=dist, torch=torch, device=dev,
-                               composite_stack=composite_stack)
+                               composite_stack=composite_stack, n_chunks=n_chunks)
 
     for _ in range(max(warmup, 1)):
         img = step()
@@ -220,6 +243,8 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     # FFT kernel alone on this rank's shard (HIP events on the launch stream)
+    if ingest:
+        iq.copy_(host_iq)
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     k0.record()
     for _ in range(10):
@@ -247,13 +272,114 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         "metric": "fft_frames_per_sec_broad_sweep_n4096", "value": frames_total * steps / wall, "unit": "frames/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "broad: 512 centre freqs x 256 frames x 4096-pt, DB5_U8_DCFIX tiles, gather to "
-                               "rank 0 + max-composite (resident input + gather regime)",
-                   "parallelism": "centre frequencies sharded x%d, one gather of u8 tiles" % world},
+        "config": {"workload": "broad: 512 centre freqs x 256 frames x 4096-pt, DB5_U8_DCFIX tiles, chunked gather "
+                               "to rank 0 overlapped with the FFT + max-composite",
+                   "regime": ("ingest: captures start in pinned host memory, H2D inside the step (one PCIe link per GPU)"
+                              if ingest else "resident: captures in HBM when the step starts (gather is xGMI-link-bound)"),
+                   "gather_chunks": n_chunks,
+                   "parallelism": "centre frequencies sharded x%d, u8 tiles gathered by grouped send/recv" % world},
         "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": plan.kernel_name, "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg},
         "stitched_pixel_max_diff_vs_numpy_guard": check,
+    }
+    plan.close()
+    return line
+
+
+def stream_block(torch, dev, block, block_samples):
+    """Block `block` of the synthetic 20 Msps stream of config C5 (seed 5): int8 Gaussian
+    sigma = 20, generated on the device from a per-block seed, so that any rank can produce any part of
+    the ONE global stream (its own frames plus the halo) without holding the rest."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5000000 + block)
+    x = torch.randn(2 * block_samples, generator=gen, device=dev) * 20.0
+    return torch.clamp(torch.round(x), -128, 127).to(torch.int8)
+
+
+def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
+    """SURVEY 8(d)/(e) config C5 as specified: ONE synthetic stream, 16384-point frames at hop 8192 (50 %
+    overlap); the frame range is cut into one contiguous piece per rank, every rank reads its samples plus
+    the N - hop = 8192-sample halo it shares with its neighbour (nothing is exchanged), and the f32 rows are
+    gathered to rank 0 chunk by chunk, overlapped with the next chunk's FFT.  Strong scaling: the stream is
+    fixed, a step is the whole stream."""
+    from frequensea_amd import fsea, sweep
+
+    n, hop = 16384, 8192
+    total_frames = args.stream_frames
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f_lo, f_hi = sweep.partition(total_frames, world, rank)
+    s_lo, s_hi = sweep.frame_sample_range(f_lo, f_hi, n, hop)
+    block_samples = 1 << 20
+    iq = torch.empty(2 * (s_hi - s_lo), dtype=torch.int8, device=dev)
+    for blk in range(s_lo // block_samples, (s_hi + block_samples - 1) // block_samples):
+        b0, b1 = blk * block_samples, (blk + 1) * block_samples
+        a, b = max(b0, s_lo), min(b1, s_hi)
+        iq[2 * (a - s_lo): 2 * (b - s_lo)] = stream_block(torch, dev, blk, block_samples)[2 * (a - b0): 2 * (b - b0)]
+    plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_MAG_F32, device=dev.index)
+    out = torch.empty((total_frames, n), dtype=torch.float32, device=dev) if rank == 0 else None
+    # rank 0 transforms its own frames straight into the gathered array; the others into a send buffer
+    rows = out[f_lo:f_hi] if rank == 0 else torch.empty((f_hi - f_lo, n), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def make_rows(a, b):
+        plan.exec_device(iq.data_ptr() + 2 * (a * hop - s_lo), b - a, rows.data_ptr() + 4 * n * (a - f_lo), flip=True,
+                         stream=stream)
+        return rows[a - f_lo: b - f_lo]
+
+    n_chunks = args.chunks if world > 1 else 1
+
+    def step():
+        return sweep.run_stft(total_frames, n, make_rows, out, dist=dist, torch=torch, device=dev, n_chunks=n_chunks)
+
+    for _ in range(max(warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for _ in range(5):
+        plan.exec_device(iq.data_ptr(), f_hi - f_lo, rows.data_ptr(), flip=True, stream=stream)
+    k1.record()
+    torch.cuda.synchronize()
+    kernel_ms = k0.elapsed_time(k1) / 5
+    if dist is not None:
+        tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(tt[0]), float(tt[1])
+    rel = None
+    if rank == 0:                                               # rows 0, 1 and the last one against numpy
+        head = stream_block(torch, dev, 0, block_samples)[: 2 * (hop + n)].cpu().numpy().view(np.uint8)
+        want = numpy_rows(head, 2, n, hop)
+        got = out[:2].cpu().numpy()
+        rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        if not rel <= 1e-6:
+            raise SystemExit("bench stft stream: rows differ from the numpy guard (rel %.3e)" % rel)
+    alg = (2 * hop + 4 * n) * (f_hi - f_lo)
+    line = {
+        "metric": "fft_frames_per_sec_stft_n16384_hop8192", "value": total_frames * steps / wall, "unit": "frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "msamples_per_sec": total_frames * steps / wall * hop / 1e6,
+        "config": {"workload": "stft16384stream: one 20 Msps-style int8 stream, %d frames of 16384 points at hop 8192, "
+                               "f32 magnitude rows gathered to rank 0" % total_frames,
+                   "regime": "resident: every rank's samples (frames + 8192-sample halo) are in HBM when the step starts",
+                   "gather_chunks": n_chunks,
+                   "parallelism": "frame ranges x%d with an N - hop halo read redundantly, rows gathered by grouped send/recv" % world},
+        "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": plan.kernel_name, "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg},
+        "parity_rel_l2_first_rows": rel,
     }
     plan.close()
     return line
@@ -329,7 +455,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="batch8192x4096", choices=sorted(WORKLOADS) + ["broad"])
+    ap.add_argument("--workload", default="batch8192x4096", choices=sorted(WORKLOADS) + ["broad", "stft16384stream"])
+    ap.add_argument("--regime", default="resident", choices=["resident", "ingest"],
+                    help="broad sweep: captures resident in HBM, or H2D ingest inside the timed region")
+    ap.add_argument("--chunks", type=int, default=8, help="chunks of the overlapped gather (broad, stft16384stream)")
+    ap.add_argument("--stream-frames", type=int, default=32767,
+                    help="stft16384stream: frames in the stream (32767 = 2^28 samples, SURVEY 8(d) C5)")
     ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -368,8 +499,9 @@ def main():
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
-    if args.workload == "broad":
-        line = run_broad(args, rank, world, dist, torch, max(1, args.steps), max(1, args.warmup))
+    if args.workload in ("broad", "stft16384stream"):
+        fn = run_broad if args.workload == "broad" else run_stft_stream
+        line = fn(args, rank, world, dist, torch, max(1, args.steps), max(1, args.warmup))
         if rank == 0:
             print(json.dumps(line))
         if dist is not None:

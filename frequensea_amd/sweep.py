@@ -1,15 +1,27 @@
-"""Multi-GPU orchestration of the fft-batch / fft-stitch sweep.
+"""Multi-GPU orchestration of the fft-batch / fft-stitch sweep and of the sharded STFT stream
+(SURVEY.md 8(e)).
 
 The reference sweeps centre frequencies one after another on one HackRF and one CPU
 (c/fft-batch-broad.c:176-206) and stitches the per-frequency tiles afterwards
 (c/fft-stitch-broad.c:62-87).  Tiles are independent, so here rank r of a one-process-per-GPU job
 takes a contiguous range of centre frequencies, turns each capture into a u8 dB tile on its own GPU
-(no data-path collective), and only the finished tiles travel: one gather to rank 0 (RCCL over xGMI
-when the backend is "nccl") followed by the max-composite of c/fft-stitch*.c:46-54 on rank 0.
+(no data-path collective), and only the finished tiles travel to rank 0, where they are
+max-composited (c/fft-stitch*.c:46-54).  The same holds for whole frames of one long capture
+(BASELINE config 5: 16384-point, 50 % overlap): rank r transforms a contiguous frame range and reads
+the N - hop samples it shares with its neighbour redundantly from the source -- no exchange -- and the
+rows travel to rank 0.
 
-The per-tile compute and the composite are passed in as callables so that the same orchestration
-runs on GPUs (frequensea_amd.fsea kernels, see bench.py) and in the world_size-2 gloo test on CPU
-(where the test supplies the oracle as the tile source).  Nothing here computes spectra itself.
+The exchange is a CHUNKED gather: every rank cuts its range into chunks, computes chunk j + 1 while
+chunk j is on the wire, and rank 0 posts the receives of one chunk index from all peers as one group
+(torch.distributed.batch_isend_irecv = one ncclGroup of ncclSend/ncclRecv when the backend is "nccl",
+i.e. RCCL: xGMI is point-to-point, every peer -> root stream rides its own link) and
+consumes chunk j while chunk j + 1 arrives.  ProcessGroupNCCL runs the transfers on its own stream
+behind the compute stream's work at the time of the call, so transfer and compute overlap without
+further plumbing; with "gloo" (the CPU tests) the same calls are plain TCP sends.
+
+The per-item compute and the consumer are passed in as callables so that the same orchestration
+runs on GPUs (frequensea_amd.fsea kernels, see bench.py) and in the world_size-2/3 gloo tests on
+CPU (where the tests supply the oracle as the source).  Nothing here computes spectra itself.
 """
 import numpy as np
 
@@ -21,50 +33,123 @@ def partition(n_items, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def chunk_ranges(lo, hi, n_chunks):
+    """[lo, hi) cut into at most n_chunks contiguous, balanced, non-empty ranges (empty list for an empty range)."""
+    count = hi - lo
+    n = max(1, min(n_chunks, count)) if count > 0 else 0
+    return [(lo + partition(count, n, j)[0], lo + partition(count, n, j)[1]) for j in range(n)]
+
+
 def stitched_width(fft_size, n_tiles, width_step):
     """IMAGE_WIDTH = FFT_SIZE + (n_tiles - 1) * WIDTH_STEP (c/fft-stitch.c:27, fft-stitch-broad.c:56)."""
     return fft_size + (n_tiles - 1) * width_step if n_tiles else 0
 
 
-def run_sweep(n_tiles, tile_shape, make_tiles, composite, dist=None, torch=None, device=None, width_step=None,
-              composite_stack=None):
-    """Shard `n_tiles` centre frequencies over the ranks of `dist`, gather the tiles to rank 0 and stitch.
+def frame_sample_range(f_lo, f_hi, n, hop):
+    """Samples [s_lo, s_hi) that frames [f_lo, f_hi) of an overlapped stream read: the last N - hop of them are
+    the halo shared with the next rank's first frame (read redundantly, not exchanged)."""
+    if f_hi <= f_lo:
+        return f_lo * hop, f_lo * hop
+    return f_lo * hop, (f_hi - 1) * hop + n
 
-    make_tiles(lo, hi) -> torch.uint8 tensor [hi-lo, H, N] on `device` (this rank's tiles, in order)
+
+def gather_chunked(n_items, item_shape, dtype, produce, consume, dist=None, torch=None, device=None, n_chunks=8):
+    """Items [0, n_items) are partitioned over the ranks; rank r computes its range chunk by chunk with
+    produce(a, b) -> tensor [b - a, *item_shape] of `dtype` on `device`, and rank 0 receives every chunk
+    and calls consume(a, b, tensor) for it (own chunks included), chunk index by chunk index.
+
+    Returns the number of bytes this rank put on the wire (0 on rank 0)."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    ranges = [chunk_ranges(*partition(n_items, world, r), n_chunks) for r in range(world)]
+    mine = ranges[rank]
+    # gloo moves host memory only: device tensors are staged through the host on both sides (the
+    # single-GPU exercise of the N > 1 control path, FSEA_BENCH_BACKEND=gloo); RCCL takes them as they are
+    staged = dist is not None and dist.get_backend() != "nccl" and device is not None and str(device) != "cpu"
+    wire = "cpu" if staged else device
+    if rank != 0:
+        pending, sent = [], 0
+        for a, b in mine:
+            t = produce(a, b).contiguous()
+            assert tuple(t.shape) == (b - a,) + tuple(item_shape) and t.dtype == dtype
+            if staged:
+                t = t.cpu()
+            pending.append((dist.isend(t, dst=0), t))      # the tensor stays alive until its send has completed
+            sent += t.numel() * t.element_size()
+        for req, _ in pending:
+            req.wait()
+        return sent
+    # rank 0: receives of chunk index j from all peers are one group; its own chunk j is computed meanwhile
+    depth = max(len(r) for r in ranges) if ranges else 0
+    inbox = []
+    for j in range(depth):
+        ops, bufs = [], []
+        for r in range(1, world):
+            if j < len(ranges[r]):
+                a, b = ranges[r][j]
+                buf = torch.empty((b - a,) + tuple(item_shape), dtype=dtype, device=wire)
+                bufs.append((a, b, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        inbox.append((reqs, bufs))
+    for j in range(depth):
+        if j < len(mine):
+            a, b = mine[j]
+            t = produce(a, b)
+            assert tuple(t.shape) == (b - a,) + tuple(item_shape) and t.dtype == dtype
+            consume(a, b, t)
+        reqs, bufs = inbox[j]
+        for req in reqs:
+            req.wait()
+        for a, b, buf in bufs:
+            consume(a, b, buf.to(device) if staged else buf)
+    return 0
+
+
+def run_sweep(n_tiles, tile_shape, make_tiles, composite, dist=None, torch=None, device=None, width_step=None,
+              composite_stack=None, n_chunks=8):
+    """Shard `n_tiles` centre frequencies over the ranks of `dist`, gather the tiles to rank 0 chunk by chunk
+    and stitch them as they arrive.
+
+    make_tiles(lo, hi) -> torch.uint8 tensor [hi-lo, H, N] on `device` (tiles lo..hi-1, in order)
     composite(image, tile, x)   max-composites one [H, N] tile into image[:, x:x+N] (rank 0 only)
-    composite_stack(image, stack, count, first_x)   optional: all `count` tiles of one rank's stack at
-                                once (tile k at first_x + k * width_step); used instead of `composite`
+    composite_stack(image, stack, count, first_x)   optional: all `count` tiles of a stack at once (tile k
+                                at first_x + k * width_step); used instead of `composite`
     Returns the stitched [H, W] torch.uint8 image on rank 0, None elsewhere.
     """
     h, n = tile_shape
     width_step = n if width_step is None else width_step
-    world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    lo, hi = partition(n_tiles, world, rank)
-    mine = make_tiles(lo, hi)
-    assert tuple(mine.shape) == (hi - lo, h, n) and mine.dtype == torch.uint8
-    per_rank = [partition(n_tiles, world, r) for r in range(world)]
-    cap = max(b - a for a, b in per_rank)
-    if world > 1:
-        # equal-sized messages: pad the short ranks' stacks by one empty tile
-        send = mine
-        if hi - lo < cap:
-            send = torch.zeros((cap, h, n), dtype=torch.uint8, device=device)
-            send[: hi - lo] = mine
-        gathered = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-        dist.gather(send.contiguous(), gather_list=gathered, dst=0)
-    else:
-        gathered = [mine]
-    if rank != 0:
-        return None
-    image = torch.zeros((h, stitched_width(n, n_tiles, width_step)), dtype=torch.uint8, device=device)
-    for r, (a, b) in enumerate(per_rank):
+    image = None
+    if rank == 0:
+        image = torch.zeros((h, stitched_width(n, n_tiles, width_step)), dtype=torch.uint8, device=device)
+
+    def consume(a, b, stack):
         if composite_stack is not None:
-            composite_stack(image, gathered[r], b - a, a * width_step)
-            continue
+            composite_stack(image, stack, b - a, a * width_step)
+            return
         for k in range(b - a):
-            composite(image, gathered[r][k], (a + k) * width_step)
+            composite(image, stack[k], (a + k) * width_step)
+
+    gather_chunked(n_tiles, (h, n), torch.uint8, make_tiles, consume, dist=dist, torch=torch, device=device,
+                   n_chunks=n_chunks)
     return image
+
+
+def run_stft(n_frames, n, make_rows, out_rows, dist=None, torch=None, device=None, n_chunks=8, dtype=None):
+    """BASELINE config 5: frames [0, n_frames) of ONE overlapped stream are cut into per-rank contiguous
+    ranges (each rank reads its samples plus the N - hop halo from the source itself); the rows are gathered
+    to rank 0 into out_rows ([n_frames, n], rank 0 only; None elsewhere).
+
+    make_rows(f_lo, f_hi) -> tensor [f_hi - f_lo, n] on `device`, the spectra of frames f_lo..f_hi-1."""
+    dtype = torch.float32 if dtype is None else dtype
+
+    def consume(a, b, rows):
+        if rows.data_ptr() != out_rows[a:b].data_ptr():     # rank 0 may produce its own rows in place
+            out_rows[a:b].copy_(rows)
+
+    return gather_chunked(n_frames, (n,), dtype, make_rows, consume, dist=dist, torch=torch, device=device,
+                          n_chunks=n_chunks)
 
 
 def numpy_tiles_to_torch(torch, tiles, device):

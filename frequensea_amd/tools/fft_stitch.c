@@ -47,6 +47,13 @@ int main(int argc, char **argv) {
     const uint32_t fft_size = broad ? 256 : 1024;
     const uint32_t sample_rate = 5000000;                      /* SAMPLE_RATE */
     if (step < 0) step = broad ? 5.0 : 2.0;                     /* FREQUENCY_STEP */
+    /* WIDTH_STEP = FFT_SIZE / (SAMPLE_RATE / FREQUENCY_STEP) in integers (c/fft-stitch.c:21): the step has to
+     * be positive and at most the sample rate, or the divisions below are by zero */
+    if (!(step > 0.0) || (uint64_t)(step * 1e6 + 0.5) > (uint64_t)sample_rate || (uint64_t)(step * 1e6 + 0.5) == 0) {
+        fprintf(stderr, "ERROR: --step must be in (0, %.1f] MHz (the tiles are %.1f MHz wide)\n", sample_rate / 1e6,
+                sample_rate / 1e6);
+        return EXIT_FAILURE;
+    }
     const uint32_t step_hz = (uint32_t)(step * 1e6 + 0.5);
     const uint32_t width_step = fft_size / (sample_rate / step_hz);
     const uint32_t n_tiles = (uint32_t)((end - start) / step + 1e-9) + 1;

@@ -28,6 +28,20 @@ def test_partition_is_contiguous_and_balanced():
     assert sweep.stitched_width(1024, 300, 512) == 154112      # c/fft-stitch.c: 1024 + 299*512
 
 
+def test_chunk_ranges_cover_the_range_in_order():
+    for lo, hi in ((0, 0), (3, 4), (0, 5), (10, 74), (7, 1000)):
+        for n_chunks in (1, 2, 8, 64):
+            ch = sweep.chunk_ranges(lo, hi, n_chunks)
+            if hi == lo:
+                assert ch == []
+                continue
+            assert ch[0][0] == lo and ch[-1][1] == hi and len(ch) <= n_chunks
+            assert all(a < b for a, b in ch) and all(ch[i][1] == ch[i + 1][0] for i in range(len(ch) - 1))
+    # a rank's frames and the halo it re-reads (BASELINE config 5: N = 16384, hop = 8192)
+    assert sweep.frame_sample_range(0, 4096, 16384, 8192) == (0, 4095 * 8192 + 16384)
+    assert sweep.frame_sample_range(4096, 8191, 16384, 8192)[0] == 4096 * 8192        # starts inside rank 0's halo
+
+
 def _tile(freq_index):
     iq = synth_iq(4000000 + freq_index, 2 * N * H)            # seed = 4e6 + f
     return O.rows(iq, H, N, mode=O.MODE_DB5_U8_DCFIX)
@@ -53,7 +67,7 @@ def _worker(rank, world, port, out_path):
             image[:, x:x + N] = torch.maximum(image[:, x:x + N], tile)
 
         img = sweep.run_sweep(TILES, (H, N), make_tiles, composite, dist=dist, torch=torch, device="cpu",
-                              width_step=STEP)
+                              width_step=STEP, n_chunks=2)      # chunked: ranks with 2 tiles send them one by one
         # the bench's timing reduction: max over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -79,6 +93,63 @@ def test_sweep_gather_and_stitch_over_gloo(tmp_path, world):
     out = str(tmp_path / "stitched.npy")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert np.array_equal(np.load(out), _expected())
+
+
+# ---- BASELINE config 5: one overlapped stream, frames sharded with a halo, rows gathered to rank 0 ----
+SN, SHOP, SFRAMES = 512, 256, 23                    # 50 % overlap, a frame count no world size divides
+
+
+def _stream():
+    return synth_iq(5, 2 * ((SFRAMES - 1) * SHOP + SN))            # seed 5
+
+
+def _stft_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        stream = _stream()
+        f_lo, f_hi = sweep.partition(SFRAMES, world, rank)
+        s_lo, s_hi = sweep.frame_sample_range(f_lo, f_hi, SN, SHOP)
+        shard = stream[2 * s_lo: 2 * s_hi].copy()                   # this rank's samples incl. the halo; nothing else
+
+        def make_rows(a, b):                                        # frames a..b-1 of the global stream
+            off = 2 * (a * SHOP - s_lo)
+            rows = O.rows(shard[off: off + 2 * ((b - a - 1) * SHOP + SN)], b - a, SN, hop=SHOP)
+            return torch.from_numpy(rows.astype(np.float32))
+
+        out = torch.zeros((SFRAMES, SN), dtype=torch.float32) if rank == 0 else None
+        sent = sweep.run_stft(SFRAMES, SN, make_rows, out, dist=dist, torch=torch, device="cpu", n_chunks=3)
+        if rank == 0:
+            assert sent == 0
+            np.save(out_path, out.numpy())
+        else:
+            assert sent == (f_hi - f_lo) * SN * 4
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stft_stream_sharded_with_halo_equals_single_process(tmp_path, world):
+    """Every rank holds only its own samples plus the N - hop halo; the gathered rows must equal the
+    single-process transform of the whole stream bit for bit."""
+    out = str(tmp_path / "rows.npy")
+    mp.spawn(_stft_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    want = O.rows(_stream(), SFRAMES, SN, hop=SHOP).astype(np.float32)
+    assert np.array_equal(np.load(out), want)
+
+
+@pytest.mark.parametrize("n_chunks", [1, 3, 8])
+def test_single_process_chunked_sweep_matches(n_chunks):
+    def make_tiles(lo, hi):
+        return torch.from_numpy(np.stack([_tile(f) for f in range(lo, hi)]))
+
+    def composite(image, tile, x):
+        image[:, x:x + N] = torch.maximum(image[:, x:x + N], tile)
+
+    img = sweep.run_sweep(TILES, (H, N), make_tiles, composite, dist=None, torch=torch, device="cpu", width_step=STEP,
+                          n_chunks=n_chunks)
+    assert np.array_equal(img.numpy(), _expected())
 
 
 def test_single_process_sweep_matches():

@@ -417,7 +417,15 @@ def _nut_u8(L, arr):
     return L.nut_buffer_new_u8(arr.size // 2, 2, arr.ctypes.data)
 
 
-def test_nrf_fft_api_history_and_shift(golden):
+@pytest.fixture(params=["host", "device"])
+def history_mode(request, monkeypatch):
+    """nrf_fft's history: the host ring (default) or the device-resident ring (NRF_FFT_HISTORY=device,
+    fsea_history_*); nrf_fft_new reads the variable.  Both must give identical buffers."""
+    monkeypatch.setenv("NRF_FFT_HISTORY", request.param)
+    return request.param
+
+
+def test_nrf_fft_api_history_and_shift(golden, history_mode):
     L = nrf.nrf_lib()
     n, h = 256, 4
     fft = L.nrf_fft_new(n, h)
@@ -446,7 +454,7 @@ def test_nrf_fft_api_history_and_shift(golden):
     L.nrf_fft_free(fft)
 
 
-def test_nrf_fft_lua_sizes_and_f64_input(golden):
+def test_nrf_fft_lua_sizes_and_f64_input(golden, history_mode):
     """The sizes the shipped Lua scenes use: (1024,1024) fft.lua:34, (128,512) fft-sea.lua:211."""
     L = nrf.nrf_lib()
     raw = golden["rf_202p500_2__flipped"]
@@ -897,3 +905,122 @@ def test_host_threads_share_and_split_plans(golden):
     assert counts == [h // 4] * 4, counts
     for b in bufs:
         L.nut_buffer_free(b)
+
+
+# ---------------------------------------------------------------------------------------------
+# the draw loops of the five FFT scenes, replayed through the C API.  No Lua
+# interpreter exists in the image; what the scripts do per rendered frame is a fixed call chain
+# (src/main.cpp:775-811 binds these C functions one to one), so the chain itself is replayed:
+#   setup():  nrf_device_new(freq, file) -> [nrf_freq_shifter_new] -> nrf_fft_new(N, H)
+#   draw():   nrf_device_get_samples_buffer -> [shifter] -> nrf_fft_process -> nrf_fft_get_buffer
+#             -> ngl_texture_update(texture, fft_buffer, W, H)
+#   retune:   nrf_device_set_frequency + nrf_fft_shift(fft, (sample_rate / 1e6) / d)   (lua/_keys.lua:154-168,
+#             lua/fft-sea.lua:137-141) with live rows in the history
+# against the committed golden rows of the recorded captures.  The consumer contract is
+# ngl_texture_update's (src/ngl.c:224-239): width * height <= buffer.length or exit, and the f64
+# buffer narrowed to f32 element by element.
+# ---------------------------------------------------------------------------------------------
+SCENES = {
+    # name: (N, H, texture W x H, shifter offset Hz or None, retune steps d in MHz as the scene's handlers make them)
+    "fft.lua": (1024, 1024, (1024, 1024), None, [0.1, -0.1, 10.0]),          # _keys.lua: d = 0.1, Shift: 10
+    "fft-shifted.lua": (1024, 1024, (1024, 1024), 0.0, [0.1]),               # shift = 0 at setup (fft-shifted.lua:38)
+    "fft-sea.lua": (128, 512, (128, 512), None, [0.1, 72.2, -0.001]),        # set_freq: arbitrary d (97.6 -> 169.8)
+    "fft-sea-auto.lua": (128, 512, (128, 512), None, [72.2, 264.3]),         # automatic hops between the listed stations
+    "fft-sea-sick.lua": (128, 128, (128, 128), None, []),                    # no retune handler
+}
+
+
+def _texture_update(L, buf, width, height):
+    """src/ngl.c:224-239 for an F64 buffer: the size check, then tex[i] = (float) data.f64[i]."""
+    c = buf.contents
+    assert width * height <= c.length, "ERROR ngl_texture_update: Invalid width / height"
+    assert c.type == nrf.NUT_BUFFER_F64 and c.channels == 1
+    size = width * height * c.channels
+    return np.ctypeslib.as_array(c.data.f64, shape=(c.length,))[:size].astype(np.float32)
+
+
+@pytest.mark.parametrize("scene", sorted(SCENES))
+def test_lua_scene_draw_loop_replay(golden, tmp_path, scene, history_mode):
+    import time
+    n, h, (tw, th), shifter_hz, retunes = SCENES[scene]
+    L = nrf.nrf_lib()
+    # a replay file of four blocks: the recorded captures' first 32 KiB (all nrf_fft_process reads for N <= 16384)
+    blocks = []
+    for key in GOLDEN_KEYS:
+        blk = np.zeros(nrf.NRF_BUFFER_SIZE_BYTES, np.uint8)
+        blk[: golden[key + "__raw"].size] = golden[key + "__raw"]
+        blocks.append(blk)
+    path = tmp_path / "replay.raw"
+    np.concatenate(blocks).tofile(path)
+    rows = [golden[key + "__mag_%d" % n] for key in GOLDEN_KEYS]          # what each block's row must be
+    fs = 5000000                                                          # the replay device's sample rate (src/nrf.c:254)
+
+    dev = L.nrf_device_new(97.0, str(path).encode())
+    L.nrf_device_set_paused(dev, 1)
+    shifter = L.nrf_freq_shifter_new(int(shifter_hz), fs) if shifter_hz is not None else None
+    fft = L.nrf_fft_new(n, h)
+    want = np.zeros((h, n))                                               # the history the reference would hold
+    shifted_samples = 0
+
+    def frame(block_index):
+        nonlocal want, shifted_samples
+        flipped = O.flip_u8(blocks[block_index])
+        deadline = time.time() + 2.0
+        while True:                                                       # the replay thread ingests at 60 Hz
+            samples = L.nrf_device_get_samples_buffer(dev)
+            got = np.ctypeslib.as_array(samples.contents.data.u8, shape=(nrf.NRF_BUFFER_SIZE_BYTES,))
+            if np.array_equal(got, flipped):
+                break
+            L.nut_buffer_free(samples)
+            assert time.time() < deadline, "replay device did not deliver block %d" % block_index
+            time.sleep(0.005)
+        if shifter is not None:
+            L.nrf_freq_shifter_process(shifter, samples)
+            sb = L.nrf_freq_shifter_get_buffer(shifter)
+            L.nrf_fft_process(fft, sb)
+            L.nut_buffer_free(sb)
+            row = O.rows_shifted(flipped[: 2 * n], 1, n, shifter_hz / fs, shifted_samples * (shifter_hz / fs), flip=False)[0]
+            shifted_samples += nrf.NRF_SAMPLES_LENGTH
+        else:
+            L.nrf_fft_process(fft, samples)
+            row = rows[block_index]
+        L.nut_buffer_free(samples)
+        want = np.vstack([row[None, :], want[:-1]])                       # src/nrf.c:616-617: newest row first
+        buf = L.nrf_fft_get_buffer(fft)
+        tex = _texture_update(L, buf, tw, th)
+        L.nut_buffer_free(buf)
+        return tex
+
+    def check(tex, exact_rows_from=None):
+        got = tex.reshape(th, tw).astype(np.float64)
+        live = np.flatnonzero(want.any(axis=1))
+        parity.check_float(got[live], want[live].astype(np.float32).astype(np.float64))
+        assert not got[[r for r in range(th) if r not in set(live)]].any()
+        # the checksum a headless run would record for this frame
+        assert abs(float(tex.sum(dtype=np.float64)) - float(want.astype(np.float32).sum(dtype=np.float64))) \
+            <= 2e-6 * max(1.0, float(np.abs(want).sum()))
+
+    k = 0
+    for _ in range(5):                                                    # five rendered frames
+        tex = frame(k % 4)
+        L.nrf_device_step(dev)
+        k += 1
+    check(tex)
+    for d in retunes:                                                     # retune with live rows, then keep drawing
+        L.nrf_device_set_frequency(dev, 97.0 + d)
+        L.nrf_fft_shift(fft, (fs / 1e6) / d)
+        O.fft_shift(want, n, h, (fs / 1e6) / d)
+        for _ in range(2):
+            tex = frame(k % 4)
+            L.nrf_device_step(dev)
+            k += 1
+        check(tex)
+    # a texture larger than the buffer is the reference's fatal error
+    buf = L.nrf_fft_get_buffer(fft)
+    with pytest.raises(AssertionError, match="Invalid width / height"):
+        _texture_update(L, buf, tw, th + 1)
+    L.nut_buffer_free(buf)
+    if shifter is not None:
+        L.nrf_freq_shifter_free(shifter)
+    L.nrf_device_free(dev)
+    L.nrf_fft_free(fft)

@@ -115,3 +115,53 @@ def test_gpu_stitch_equals_the_reference_binary(tmp_path):
                     "--dir", str(tmp_path)], capture_output=True, text=True, check=True)
     ours = _read(L, tmp_path / "broad-stitched-900-915.png")
     assert ours.shape == ref.shape == (4096, 1024) and np.array_equal(ours, ref)
+
+
+@pytest.mark.parametrize("devices,chunk", [("0", 4), ("0,0", 1), ("0,0,0", 2)])
+def test_multi_member_sweep_equals_batch_plus_stitch(tmp_path, devices, chunk):
+    """fsea-fft-sweep: one host thread per member, tiles gathered chunk by chunk to member 0 and stitched
+    there (RCCL between distinct GPUs; members sharing the one GPU of this box use the copy backend, same
+    control path).  Its tiles and its stitched image must equal fsea-fft-batch followed by fsea-fft-stitch,
+    gate included (the all-zero capture: no PNG, nothing in the image)."""
+    n, rows, skip = 256, 120, 3
+    freqs = [660, 665, 670, 675, 680]
+    for f in freqs:
+        _capture(tmp_path / ("c%d.raw" % f), f, rows + skip, zero=(f == 670))
+    caps = ["%d=%s" % (f, tmp_path / ("c%d.raw" % f)) for f in freqs]
+    ref_dir, out_dir = tmp_path / "ref", tmp_path / "sweep"
+    ref_dir.mkdir()
+    out_dir.mkdir()
+    subprocess.run([os.path.join(BIN, "fsea-fft-batch"), "--broad", "--rows", str(rows), "--skip", str(skip),
+                    "--out", str(ref_dir)] + caps, capture_output=True, text=True, check=True)
+    res = subprocess.run([os.path.join(BIN, "fsea-fft-sweep"), "--broad", "--devices", devices, "--chunk", str(chunk),
+                          "--rows", str(rows), "--skip", str(skip), "--out", str(out_dir)] + caps,
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert "Not interesting. Skipping..." in res.stdout and not os.path.exists(out_dir / "broad-670.png")
+    want = np.zeros((rows, n * len(freqs)), np.uint8)
+    for k, f in enumerate(freqs):
+        if f == 670:
+            continue
+        tile = _png(ref_dir / ("broad-%d.png" % f))
+        assert np.array_equal(_png(out_dir / ("broad-%d.png" % f)), tile)
+        O.composite_max(want, np.ascontiguousarray(tile), k * n)
+    assert np.array_equal(_png(out_dir / "broad-stitched-660-680.png"), want)
+
+
+def test_multi_member_narrow_sweep_with_overlap(tmp_path):
+    """1024-point tiles at 2 MHz steps overlap by half (c/fft-stitch.c:21-25): neighbouring members' tiles
+    max-composite into the same columns on the root."""
+    n, rows = 1024, 33
+    freqs = [1802.0, 1804.0, 1806.0, 1808.0]
+    for i in range(4):
+        _capture(tmp_path / ("n%d.raw" % i), 50 + i, rows + 10)
+    caps = ["%.4f=%s" % (f, tmp_path / ("n%d.raw" % i)) for i, f in enumerate(freqs)]
+    res = subprocess.run([os.path.join(BIN, "fsea-fft-sweep"), "--devices", "0,0,0", "--chunk", "1", "--rows", str(rows),
+                          "--out", str(tmp_path)] + caps, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert "Gather backend: copy" in res.stdout
+    step = 512
+    want = np.zeros((rows, n + 3 * step), np.uint8)
+    for k, f in enumerate(freqs):
+        O.composite_max(want, np.ascontiguousarray(_png(tmp_path / ("fft-%.4f.png" % f))), k * step)
+    assert np.array_equal(_png(tmp_path / "fft-stitched-1802.0000-1808.0000.png"), want)

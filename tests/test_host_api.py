@@ -46,6 +46,24 @@ def test_tuning_library_is_a_superset_and_the_product_has_no_variants():
     assert "fsea_abl8192_io_u8_mag" in tuned and "fsea_fft8192v2_u8_mag" in tuned
 
 
+def test_comm_library_exports_every_declared_symbol():
+    """include/fsea_comm.h = libfsea_rccl.so (the multi-GPU gather: RCCL grouped send/recv)."""
+    path = os.path.join(os.path.dirname(fsea.lib_path()), "libfsea_rccl.so")
+    L = ctypes.CDLL(path)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fsea_comm.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b(fsea_comm_[a-z0-9_]+)\s*\(", text))
+    assert names == {"fsea_comm_create", "fsea_comm_destroy", "fsea_comm_size", "fsea_comm_backend",
+                     "fsea_comm_stream_create", "fsea_comm_stream_destroy", "fsea_comm_gather", "fsea_comm_barrier",
+                     "fsea_comm_last_error"}
+    for name in names:
+        assert hasattr(L, name), name
+    import subprocess
+    deps = subprocess.check_output(["ldd", path]).decode()
+    assert "librccl" in deps
+    for lib in ("libfsea_hip.so", "libfsea_nrf.so"):               # the product libraries do not pull RCCL in
+        assert "rccl" not in subprocess.check_output(["ldd", os.path.join(os.path.dirname(path), lib)]).decode()
+
+
 def test_nrf_exports_every_declared_symbol():
     L = ctypes.CDLL(nrf.lib_path())
     for header, listed in (("nut.h", nrf.NUT_EXPORTS), ("nrf.h", nrf.NRF_EXPORTS)):
