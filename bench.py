@@ -214,7 +214,7 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         return px[a - lo: b - lo]
 
     def composite(image, tile, x):
-        fsea.composite_max_device(image.data_ptr(), tile.data_ptr(), x, 0, n, rows, image.shape[1], n,
+        fsea.composite_max_device(image.data_ptr(), tile.data_ptr(), x, 0, n, rows, image.shape[1], image.shape[0], n,
                                   device=dev.index, stream=stream)
 
     def composite_stack(image, stack, count, first_x):

@@ -319,9 +319,11 @@ unsigned *counter_slot(fsea_plan *p, hipStream_t s) {
 int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
            hipStream_t s, double rot_delta = 0.0, double rot_phase0 = 0.0) {
     if (n_frames == 0) return FSEA_OK;
-    const int kind = pick_kind(in_kind, mode, flip);
+    int kind = pick_kind(in_kind, mode, flip);
     const fsea::KernelEntry *e = p->entry;
-    if (!e->fn[kind]) {  // tuning variants carry the u8 MAG and run-time-mode kernels only
+    // tuning variants carry the u8 MAG and run-time-mode kernels only: their pixel modes run the latter
+    if (!e->fn[kind] && (kind == fsea::K_U8_DB5 || kind == fsea::K_U8_DB10)) kind = fsea::K_U8;
+    if (!e->fn[kind]) {
         return fail(FSEA_EINVAL, "kernel variant '%s' has no entry point for this input kind", e->variant);
     }
     fsea::FftArgs a;
@@ -405,7 +407,11 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     p->device = device;
     p->entry = e;
     p->num_cu = prop.multiProcessorCount;
-    p->kernel_name = e->name[pick_kind(fsea::IN_U8, mode, 1)];  // the kernel raw int8 input (flip) launches
+    {
+        int k = pick_kind(fsea::IN_U8, mode, 1);  // the kernel raw int8 input (flip) launches
+        if (!e->fn[k]) k = fsea::K_U8;
+        p->kernel_name = e->name[k];
+    }
 #ifdef FSEA_TUNE
     if (std::getenv("FSEA_TRACE")) {
         if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 32 * sizeof(unsigned long long)) != hipSuccess) {
@@ -492,7 +498,9 @@ const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_nam
 
 int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned *block, size_t *lds_bytes) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
-    if (grid) *grid = grid_for(p, p->entry, p->occ[pick_kind(fsea::IN_U8, p->mode, 1)], n_frames);
+    int k = pick_kind(fsea::IN_U8, p->mode, 1);
+    if (!p->entry->fn[k]) k = fsea::K_U8;
+    if (grid) *grid = grid_for(p, p->entry, p->occ[k], n_frames);
     if (block) *block = (unsigned)p->entry->wg;
     if (lds_bytes) *lds_bytes = p->entry->lds_bytes;
     return FSEA_OK;
@@ -776,11 +784,16 @@ int fsea_mean_magnitude_u8_device(fsea_plan *p, const void *d_iq, size_t n_frame
 }
 
 int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x, uint32_t dst_y, uint32_t width,
-                              uint32_t height, uint32_t dst_stride, uint32_t src_stride, int device, void *stream) {
+                              uint32_t height, uint32_t dst_stride, uint32_t dst_height, uint32_t src_stride, int device,
+                              void *stream) {
     if (!d_dst || !d_src) return fail(FSEA_EINVAL, "NULL buffer");
     if (width == 0 || height == 0) return FSEA_OK;
     if ((uint64_t)dst_x + (uint64_t)width > (uint64_t)dst_stride || width > src_stride) {
         return fail(FSEA_EINVAL, "tile does not fit the row stride");
+    }
+    if ((uint64_t)dst_y + (uint64_t)height > (uint64_t)dst_height) {
+        return fail(FSEA_EINVAL, "tile rows %u..%llu do not fit the %u destination rows", dst_y,
+                    (unsigned long long)dst_y + height, dst_height);
     }
     FSEA_ON_DEVICE(device);
     const unsigned bx = 64;
@@ -874,6 +887,26 @@ int fsea_time_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, in
     FSEA_HIP(hipEventRecord(p->ev0, s));
     for (int i = 0; i < reps; ++i) {
         rc = launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, d_out, s);
+        if (rc) return rc;
+    }
+    FSEA_HIP(hipEventRecord(p->ev1, s));
+    FSEA_HIP(hipEventSynchronize(p->ev1));
+    float ms = 0.f;
+    FSEA_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    *avg_ms = ms / (float)reps;
+    return FSEA_OK;
+}
+
+// The same over n_sets independent buffer sets used in rotation, so that no launch finds its
+// bytes in the 256 MiB Infinity Cache (the streaming regime bench.py measures).
+int fsea_time_exec_u8_rotating(fsea_plan *p, void *const *d_iq, void *const *d_out, int n_sets, size_t n_frames,
+                               int flip, void *stream, int reps, float *avg_ms) {
+    if (!p || !d_iq || !d_out || n_sets <= 0 || reps <= 0 || !avg_ms) return fail(FSEA_EINVAL, "bad arguments");
+    FSEA_ON_DEVICE(p->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FSEA_HIP(hipEventRecord(p->ev0, s));
+    for (int i = 0; i < reps; ++i) {
+        int rc = launch(p, fsea::IN_U8, d_iq[i % n_sets], n_frames, flip, p->mode, d_out[i % n_sets], s);
         if (rc) return rc;
     }
     FSEA_HIP(hipEventRecord(p->ev1, s));

@@ -18,6 +18,24 @@
 // OPT 512 (late ticket wait) and OPT 1024 (static priority for one of the two co-resident workgroups)
 #define FSEA_CFG_8192_TK 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 670
 #define FSEA_CFG_8192_PR 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 1182
+// cache policy of the input loads / output stores (OPT 4096 nt stores, 8192 sc1, 16384 sc0, 32768 nt loads):
+// "cp0" = default policy for both (the round-2 kernel before the policy was chosen), then the alternatives
+#define FSEA_CFG_8192_CP0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 158
+#define FSEA_CFG_8192_STNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 4254
+#define FSEA_CFG_8192_STSC1 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 8350
+#define FSEA_CFG_8192_STSC01 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 24734
+#define FSEA_CFG_8192_STSC1NT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 12446
+#define FSEA_CFG_8192_LDNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 32926
+#define FSEA_CFG_16384_CP0 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 136
+#define FSEA_CFG_16384_STNT 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 4232
+#define FSEA_CFG_4096_CP0 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 10
+#define FSEA_CFG_4096_STNT 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 4106
+#define FSEA_CFG_2048_CP0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 14
+#define FSEA_CFG_2048_STNT 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 4110
+#define FSEA_CFG_1024_CP0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 10
+#define FSEA_CFG_1024_LDSTNT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 36874
+#define FSEA_CFG_256_CP0 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true, 0, 0
+#define FSEA_CFG_256_LDSTNT 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true, 0, 36864
 // V2 schedule (OPT 64): first exchange inside each wavefront, two barriers per frame; with its
 // measurement-only ablations (8: static units + early prefetch, 16: V1 load mapping, wrong results,
 // 32: no first exchange, wrong results)

@@ -385,31 +385,31 @@ __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, con
     }
 }
 
-template <int C>
+template <int C, int AUX = 0>
 __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, const uint8_t *v) {
     if constexpr (C == 1) {
-        __builtin_amdgcn_raw_buffer_store_b8(v[0], rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b8(v[0], rs, voff, soff, AUX);
     } else if constexpr (C == 2) {
-        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(v[0] | (v[1] << 8)), rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(v[0] | (v[1] << 8)), rs, voff, soff, AUX);
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
             const uint32_t w = (uint32_t)v[c] | ((uint32_t)v[c + 1] << 8) | ((uint32_t)v[c + 2] << 16) |
                                ((uint32_t)v[c + 3] << 24);
-            __builtin_amdgcn_raw_buffer_store_b32(w, rs, voff + c, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(w, rs, voff + c, soff, AUX);
         }
     }
 }
 
-template <int C>
+template <int C, int AUX = 0>
 __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, const cf *v) {
     if constexpr (C == 1) {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0][0]), f2u(v[0][1])}, rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0][0]), f2u(v[0][1])}, rs, voff, soff, AUX);
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 2) {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c][0]), f2u(v[c][1]), f2u(v[c + 1][0]), f2u(v[c + 1][1])},
-                                                   rs, voff + 8 * c, soff, 0);
+                                                   rs, voff + 8 * c, soff, AUX);
         }
     }
 }
@@ -513,6 +513,11 @@ struct FftKernel {
     static constexpr bool BATCH_READS = (Cfg::OPT & 2) != 0;
     static constexpr bool TW_HOIST = (Cfg::OPT & 4) != 0;
     static constexpr bool TW_FUSE = (Cfg::OPT & 8) != 0 && (Cfg::ABL & 4) == 0;
+    // OPT 4096 / 8192 / 16384: cache policy of the f32 row stores (measurement variants): nt (streaming),
+    // sc1 (write through the XCD's L2 and drop the line), sc0 sc1
+    static constexpr int ST_AUX = ((Cfg::OPT & 4096) ? 2 : 0) | ((Cfg::OPT & 8192) ? 16 : 0) | ((Cfg::OPT & 16384) ? 1 : 0);
+    // OPT 32768: the input loads are streaming (nt) as well
+    static constexpr int LD_AUX = (Cfg::OPT & 32768) ? 2 : 0;
     static constexpr bool DEFER = (Cfg::OPT & 128) != 0 && NP == 3;
     static constexpr bool TK_LATE = (Cfg::OPT & 512) != 0 && NP >= 3 && !ONE_WAVE && (Cfg::ABL & 2) == 0;
     static constexpr bool MI = (Cfg::OPT & 256) == 0;  // OPT 256: the +-i butterflies as packed FMAs by (+-1, -+1) (round-1 form)
@@ -575,27 +580,27 @@ struct FftKernel {
         for (int r = 0; r < R0; ++r) {
             const uint32_t soff = (uint32_t)(r * STRIDE) * IN_BPS;
             if constexpr (IN == IN_U8) {
-                if constexpr (C0 == 1) raw[r].w = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
-                if constexpr (C0 == 2) raw[r].w = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+                if constexpr (C0 == 1) raw[r].w = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, LD_AUX);
+                if constexpr (C0 == 2) raw[r].w = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, LD_AUX);
                 if constexpr (C0 == 4) {
-                    const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, LD_AUX);
                     raw[r].w.x = q[0];
                     raw[r].w.y = q[1];
                 }
                 if constexpr (C0 == 8) {
-                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, LD_AUX);
                     raw[r].w.x = q[0];
                     raw[r].w.y = q[1];
                     raw[r].w.z = q[2];
                     raw[r].w.w = q[3];
                 }
             } else if constexpr (C0 == 1) {
-                const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+                const auto q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, LD_AUX);
                 raw[r].w[0] = cf{u2f(q[0]), u2f(q[1])};
             } else {
 #pragma unroll
                 for (int c = 0; c < C0; c += 2) {
-                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 8 * c, soff, 0);
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 8 * c, soff, LD_AUX);
                     raw[r].w[c] = cf{u2f(q[0]), u2f(q[1])};
                     raw[r].w[c + 1] = cf{u2f(q[2]), u2f(q[3])};
                 }
@@ -774,7 +779,7 @@ struct FftKernel {
                 cf z[CL];
 #pragma unroll
                 for (int c = 0; c < CL; ++c) z[c] = v[r * CL + c] * cf{SE, SE};
-                bst<CL>(out, voff, (uint32_t)(r * NsL) * 8u, z);
+                bst<CL, ST_AUX>(out, voff, (uint32_t)(r * NsL) * 8u, z);
             }
         } else if (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) {
             // 10*log10(p + 1e-20) * s = (10 s log10(2)) * log2(p + 1e-20)
@@ -802,7 +807,7 @@ struct FftKernel {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + c, soff, px + c);
                 } else {
-                    bst<CL>(out, voff, soff, px);
+                    bst<CL, ST_AUX>(out, voff, soff, px);
                 }
                 if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + CL, soff, px + (CL - 1));
             }
@@ -831,7 +836,7 @@ struct FftKernel {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);
                 } else {
-                    bst<CL>(out, voff, soff, m);
+                    bst<CL, ST_AUX>(out, voff, soff, m);
                 }
                 if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + 4 * CL, soff, m + (CL - 1));
             }

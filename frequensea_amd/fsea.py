@@ -31,7 +31,8 @@ EXPORTS = [
     "fsea_history_shift", "fsea_history_get_f64",
 ]
 # include/fsea_tune.h: only libfsea_hip_tune.so (scripts/tune.py and friends) has these
-TUNE_EXPORTS = ["fsea_plan_create_variant", "fsea_time_exec_u8_device", "fsea_plan_read_trace"]
+TUNE_EXPORTS = ["fsea_plan_create_variant", "fsea_time_exec_u8_device", "fsea_time_exec_u8_rotating",
+                "fsea_plan_read_trace"]
 
 
 class FseaError(RuntimeError):
@@ -93,6 +94,8 @@ def hip_lib():
             L.fsea_plan_create_variant.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.c_char_p]
             L.fsea_time_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp, ci, ctypes.POINTER(ctypes.c_float)]
             L.fsea_plan_read_trace.argtypes = [vp, vp, ctypes.c_uint]
+            L.fsea_time_exec_u8_rotating.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, sz, ci, vp, ci,
+                                                     ctypes.POINTER(ctypes.c_float)]
         L.fsea_plan_destroy.argtypes = [vp]
         L.fsea_plan_grid.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
                                      ctypes.POINTER(sz)]
@@ -107,7 +110,7 @@ def hip_lib():
         L.fsea_exec_u8_shifted_device.argtypes = [vp, vp, sz, ci, ctypes.c_double, ctypes.c_double, vp, vp]
         L.fsea_exec_u8_shifted_host.argtypes = [vp, vp, sz, ci, ctypes.c_double, ctypes.c_double, vp]
         L.fsea_mean_magnitude_u8_device.argtypes = [vp, vp, sz, ci, ctypes.POINTER(ctypes.c_double), vp]
-        L.fsea_composite_max_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 6 + [ci, vp]
+        L.fsea_composite_max_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 7 + [ci, vp]
         L.fsea_stitch_tiles_device.argtypes = [vp, vp] + [ctypes.c_uint32] * 6 + [ci, vp]
         L.fsea_device_alloc.argtypes = [ci, sz, ctypes.POINTER(vp)]
         L.fsea_device_free.argtypes = [ci, vp]
@@ -195,6 +198,16 @@ class Plan:
                                                 stream or None, reps, ctypes.byref(ms)))
         return ms.value
 
+    def time_rotating(self, d_iq_ptrs, n_frames, d_out_ptrs, reps, flip=True, stream=0):
+        """Tuning library only (fsea_time_exec_u8_rotating): launch i uses buffer set i % len(sets)."""
+        n = len(d_iq_ptrs)
+        ins = (ctypes.c_void_p * n)(*[p.value if isinstance(p, ctypes.c_void_p) else p for p in d_iq_ptrs])
+        outs = (ctypes.c_void_p * n)(*[p.value if isinstance(p, ctypes.c_void_p) else p for p in d_out_ptrs])
+        ms = ctypes.c_float(0)
+        _check(self._L.fsea_time_exec_u8_rotating(self._p, ins, outs, n, n_frames, int(bool(flip)), stream or None, reps,
+                                                  ctypes.byref(ms)))
+        return ms.value
+
     def synchronize(self, stream=0):
         _check(self._L.fsea_stream_synchronize(self._p, stream or None))
 
@@ -238,8 +251,9 @@ class Plan:
         return m.value
 
 
-def composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride, src_stride, device=0, stream=0):
-    _check(hip_lib().fsea_composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride,
+def composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride, dst_height, src_stride, device=0,
+                         stream=0):
+    _check(hip_lib().fsea_composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride, dst_height,
                                                src_stride, device, stream or None))
 
 

@@ -5,6 +5,7 @@
  * hline) and :191-217 (banner, ticks, labels).  The tick positions are doubles stepped by a
  * fractional pixel count and truncated when passed as uint32_t, exactly as the reference does.
  */
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -114,6 +115,71 @@ int img_draw_frequency_axis(uint8_t *buffer, uint32_t image_width, uint32_t imag
                 labelled++;
             }
             freq += cfg->major_tick_rate;
+        }
+    }
+    return labelled;
+}
+
+/* c/add-markers.c:136-141: position of an absolute frequency on the poster; frequencies left of the
+ * image are skipped (the reference's unsigned subtraction wraps there and fails its `x > 0 && x < width`
+ * test by way of an out-of-range double -> int conversion) */
+static int markers_frequency_to_x(uint32_t image_width, uint64_t real_start, uint64_t real_range, uint64_t freq) {
+    if (freq < real_start) return -1;
+    return (int)round((double)(freq - real_start) / (double)real_range * image_width);
+}
+
+int img_draw_broad_markers(uint8_t *buffer, uint32_t image_width, const img_markers_config *cfg) {
+    const uint32_t out_height = cfg->header_height + cfg->source_height + cfg->footer_height;
+    const uint64_t real_start = cfg->frequency_start - (cfg->sample_rate / 2);
+    const uint64_t real_end = cfg->frequency_end + (cfg->sample_rate / 2);
+    const uint64_t real_range = real_end - real_start;
+    const uint32_t header_bottom = cfg->header_height;
+    uint32_t footer_top = cfg->header_height + cfg->source_height;
+    const uint32_t footer_bottom = out_height - 1;
+    /* c/add-markers.c:196-201: white lines at header bottom + footer top */
+    for (uint32_t i = 0; i < 10; i++) {
+        img_hline(buffer, image_width, out_height, 0, header_bottom - i, image_width, cfg->line_color);
+        img_hline(buffer, image_width, out_height, 0, footer_top + i, image_width, cfg->line_color);
+    }
+    footer_top += 10;
+    /* :203-212 minor ticks, three pixels wide */
+    if (cfg->minor_tick_rate > 0) {
+        for (uint64_t freq = 0; freq < real_end; freq += cfg->minor_tick_rate) {
+            const int x = markers_frequency_to_x(image_width, real_start, real_range, freq);
+            if (x > 0 && x < (int)image_width) {
+                for (int dx = -1; dx <= 1; dx++) {
+                    img_vline(buffer, image_width, out_height, (uint32_t)(x + dx), footer_top, footer_top + cfg->minor_tick_height,
+                              cfg->line_color);
+                    img_vline(buffer, image_width, out_height, (uint32_t)(x + dx),
+                              footer_bottom - cfg->minor_tick_height - cfg->footer_bleed, footer_bottom + 1, cfg->line_color);
+                }
+            }
+        }
+    }
+    /* :214-230 major ticks, five pixels wide, and their labels */
+    int labelled = 0;
+    const uint32_t labels_y = cfg->source_height + cfg->header_height +
+                              (cfg->footer_height / 2 - cfg->font_size_px / 2 - cfg->footer_bleed / 2);
+    if (cfg->major_tick_rate > 0) {
+        for (uint64_t freq = 0; freq < real_end; freq += cfg->major_tick_rate) {
+            const int x = markers_frequency_to_x(image_width, real_start, real_range, freq);
+            if (x > 0 && x < (int)image_width) {
+                for (int dx = -2; dx <= 2; dx++) {
+                    img_vline(buffer, image_width, out_height, (uint32_t)(x + dx), footer_top, footer_top + cfg->major_tick_height,
+                              cfg->line_color);
+                    img_vline(buffer, image_width, out_height, (uint32_t)(x + dx),
+                              footer_bottom - cfg->major_tick_height - cfg->footer_bleed, footer_bottom + 1, cfg->line_color);
+                }
+                if (freq > real_start && freq < real_end) {
+                    if (cfg->font_size_px > 0) {
+                        char text[64];
+                        snprintf(text, sizeof(text), "%.2f", (double)freq / 1e6);
+                        img_draw_text(buffer, image_width, out_height, text, x, (int)labels_y, (int)cfg->font_size_px,
+                                      cfg->line_color);
+                    }
+                    labelled++;
+                }
+            }
         }
     }
     return labelled;

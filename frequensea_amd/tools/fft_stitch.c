@@ -93,7 +93,7 @@ int main(int argc, char **argv) {
             tile_cap = bytes;
         }
         if (fsea_copy_to_device(device, d_tile, tile, bytes) != 0) die("fsea_copy_to_device");
-        if (fsea_composite_max_device(d_image, d_tile, k * width_step, 0, fft_size, image_height, image_width,
+        if (fsea_composite_max_device(d_image, d_tile, k * width_step, 0, fft_size, image_height, image_width, image_height,
                                       fft_size, device, NULL) != 0) {
             die("fsea_composite_max_device");
         }

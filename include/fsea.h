@@ -146,11 +146,13 @@ int fsea_history_get_f64(fsea_history *history, double *out);
 int fsea_mean_magnitude_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
                                   int flip, double *mean, void *stream);
 
-/* dst[y][dst_x + j] = max(dst, src[y][j]) for a width x height u8 tile
- * (c/fft-stitch.c:46-54).  Device pointers; asynchronous on `stream`. */
+/* dst[dst_y + y][dst_x + j] = max(dst, src[y][j]) for a width x height u8 tile
+ * (c/fft-stitch.c:46-54).  dst is dst_height rows of dst_stride pixels; a tile that does not lie
+ * inside it is rejected with FSEA_EINVAL (nothing is written).  Device pointers; asynchronous on
+ * `stream`. */
 int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x,
                               uint32_t dst_y, uint32_t width, uint32_t height,
-                              uint32_t dst_stride, uint32_t src_stride, int device,
+                              uint32_t dst_stride, uint32_t dst_height, uint32_t src_stride, int device,
                               void *stream);
 
 /* The whole stitch loop of c/fft-stitch*.c:167-189 for a contiguous stack of tiles

@@ -29,6 +29,11 @@ int fsea_time_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
                              int flip, void *d_out, void *stream, int reps,
                              float *avg_ms);
 
+/* The same over n_sets independent buffer sets used in rotation (launch i uses set i % n_sets): with
+ * more than 256 MiB in flight no launch is served from the Infinity Cache -- the streaming regime. */
+int fsea_time_exec_u8_rotating(fsea_plan *plan, void *const *d_iq, void *const *d_out, int n_sets,
+                               size_t n_frames, int flip, void *stream, int reps, float *avg_ms);
+
 /* When the environment variable FSEA_TRACE is set at plan creation, every launch records per
  * workgroup {wall-clock start, end (100 MHz ticks), shader-clock start, end, HW_ID, XCC_ID,
  * prologue done, first pass 0 done, end of iteration 0..23}; this copies the [n_workgroups][32]

@@ -44,6 +44,33 @@ typedef struct {
 int img_draw_frequency_axis(uint8_t *buffer, uint32_t image_width, uint32_t image_height,
                             const img_axis_config *cfg);
 
+/* Header + footer of the broad sweep poster (c/add-markers.c:143-243): the stitched image sits between a
+ * header and a footer; ten border lines close the header at its bottom and open the footer at its top;
+ * the footer carries minor ticks (3 px wide) and major ticks (5 px wide) at absolute frequencies, from its
+ * top edge downwards and from its bottom edge (minus the print bleed) upwards, and a "%.2f" MHz label per
+ * major tick inside the covered range.  The reference hard-codes one poster size (23693 x 7157) and
+ * asserts it; here the geometry comes from the caller. */
+typedef struct {
+    uint32_t source_height;    /* rows of the stitched image placed at row header_height */
+    uint32_t header_height;    /* HEADER_HEIGHT 300 */
+    uint32_t footer_height;    /* FOOTER_HEIGHT 300 */
+    uint32_t footer_bleed;     /* FOOTER_BLEED 35 */
+    uint32_t sample_rate;      /* SAMPLE_RATE 5e6: the image spans start - rate/2 ... end + rate/2 */
+    uint64_t frequency_start;  /* centre frequency of the first tile, Hz */
+    uint64_t frequency_end;    /* centre frequency of the last tile, Hz */
+    uint32_t minor_tick_rate;  /* 1e6 */
+    uint32_t minor_tick_height;/* 30 */
+    uint32_t major_tick_rate;  /* 50e6 */
+    uint32_t major_tick_height;/* 60 */
+    uint32_t font_size_px;     /* 64; 0 = no labels */
+    uint8_t line_color;        /* 255 */
+} img_markers_config;
+
+/* Draws borders, ticks and labels into buffer[header + source + footer][image_width] (the stitched image
+ * must already be in place; its rows are not touched except by the header's border line at row
+ * header_height, as in the reference).  Returns the number of labels drawn. */
+int img_draw_broad_markers(uint8_t *buffer, uint32_t image_width, const img_markers_config *cfg);
+
 /* Dot-matrix text (digits, '.', '-'): each font cell is scaled to height_px rows; (x, y) is the
  * top-left corner.  Pixels are max-composited like the reference's glyph bitmaps
  * (c/fft-stitch.c:151).  Returns the advance in pixels. */

@@ -301,3 +301,58 @@ def frequency_axis(image_width, image_height, rows_, fft_size, sample_rate, freq
         freq += major_tick_rate
         x += major
     return img, labels
+
+
+def broad_markers(source, header, footer, frequency_start, frequency_end, sample_rate=5000000, footer_bleed=35,
+                  minor_tick_rate=1000000, minor_tick_height=30, major_tick_rate=50000000, major_tick_height=60,
+                  font_size_px=64, line_color=255):
+    """Header + footer of the broad sweep poster, numpy restatement of /root/reference/c/add-markers.c:136-230
+    without the glyphs (the geometry taken from `source` instead of the reference's asserted 23693 x 7157):
+    returns (image [header + H + footer][W] with the source in place, border lines and ticks drawn,
+    [(x, y, "%.2f" label)]).  img_pixel_put never writes column 0 / row 0 (c/add-markers.c:32-36) and
+    img_vline skips x > stride (:38-43)."""
+    h, w = source.shape
+    out_h = header + h + footer
+    img = np.zeros((out_h, w), np.uint8)
+    img[header:header + h] = np.maximum(img[header:header + h], source)
+
+    def hline(y, x1, x2):
+        if 0 < y < out_h:
+            img[y, max(x1, 1):min(x2, w)] = line_color
+
+    def vline(x, y1, y2):
+        if 0 < x < w:
+            img[max(y1, 1):min(y2, out_h), x] = line_color
+
+    real_start = frequency_start - sample_rate // 2
+    real_end = frequency_end + sample_rate // 2
+    real_range = real_end - real_start
+    header_bottom, footer_top, footer_bottom = header, header + h, out_h - 1
+    for i in range(10):
+        hline(header_bottom - i, 0, w)
+        hline(footer_top + i, 0, w)
+    footer_top += 10
+
+    def to_x(freq):
+        if freq < real_start:
+            return -1
+        v = (freq - real_start) / float(real_range) * w
+        return int(np.floor(v + 0.5)) if v >= 0 else -1                # C round(): half away from zero
+
+    for freq in range(0, real_end, minor_tick_rate):
+        x = to_x(freq)
+        if 0 < x < w:
+            for dx in (-1, 0, 1):
+                vline(x + dx, footer_top, footer_top + minor_tick_height)
+                vline(x + dx, footer_bottom - minor_tick_height - footer_bleed, footer_bottom + 1)
+    labels = []
+    labels_y = h + header + (footer // 2 - font_size_px // 2 - footer_bleed // 2)
+    for freq in range(0, real_end, major_tick_rate):
+        x = to_x(freq)
+        if 0 < x < w:
+            for dx in (-2, -1, 0, 1, 2):
+                vline(x + dx, footer_top, footer_top + major_tick_height)
+                vline(x + dx, footer_bottom - major_tick_height - footer_bleed, footer_bottom + 1)
+            if real_start < freq < real_end:
+                labels.append((x, labels_y, "%.2f" % (freq / 1e6)))
+    return img, labels

@@ -24,6 +24,11 @@ VARIANTS = {
 }
 TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch
 ROUNDS = 7
+# TUNE_SETS=k: k independent buffer sets used in rotation (streaming regime, nothing served from the
+# Infinity Cache); TUNE_FRAMES=f: frames per launch (default: TOTAL_SAMPLES / N); TUNE_MODE=m: epilogue mode
+SETS = int(os.environ.get("TUNE_SETS", "1"))
+MODE = int(os.environ.get("TUNE_MODE", "0"))
+OUT_BYTES = {0: 4, 1: 1, 2: 1, 3: 8, 4: 4, 5: 4}[MODE]
 
 
 def dev_alloc(nbytes):
@@ -39,11 +44,14 @@ def main():
     host = rng.integers(-70, 70, 2 * TOTAL_SAMPLES, dtype=np.int8).view(np.uint8)
     if os.environ.get("TUNE_CONST_INPUT"):  # how much of the time is data-dependent (power)?
         host[:] = 0x80
-    d_in = dev_alloc(host.nbytes)
-    d_out = dev_alloc(4 * TOTAL_SAMPLES)
-    fsea._check(L.fsea_copy_to_device(0, d_in, host.ctypes.data, host.nbytes))
+    per_set = TOTAL_SAMPLES if not os.environ.get("TUNE_FRAMES") else int(os.environ["TUNE_FRAMES"]) * max(sizes)
+    d_ins = [dev_alloc(2 * per_set) for _ in range(SETS)]
+    d_outs = [dev_alloc(max(4, OUT_BYTES) * per_set) for _ in range(SETS)]
+    for d in d_ins:
+        fsea._check(L.fsea_copy_to_device(0, d, host.ctypes.data, 2 * per_set))
+    d_in, d_out = d_ins[0], d_outs[0]
     for n in sizes:
-        frames = TOTAL_SAMPLES // n
+        frames = int(os.environ["TUNE_FRAMES"]) if os.environ.get("TUNE_FRAMES") else TOTAL_SAMPLES // n
         u = (host[: 2 * n * 3] ^ np.uint8(0x80)).astype(np.float64).reshape(3, n, 2) / 256.0
         want = np.abs(np.fft.fft((u[..., 0] + 1j * u[..., 1]) * (1.0 - 2.0 * (np.arange(n) & 1)), axis=1))
         want[:, n // 2] = want[:, n // 2 - 1]                 # src/nrf.c:599-630
@@ -53,34 +61,39 @@ def main():
             names = ["" if v == "-" else v for v in os.environ["TUNE_VARIANTS"].split(",")]
         for var in names:
             try:
-                plans.append((var, fsea.Plan(n, variant=var)))
+                plans.append((var, fsea.Plan(n, variant=var, mode=MODE)))
             except fsea.FseaError as e:
                 print("N=%d variant=%-6s unavailable: %s" % (n, var, e))
         # warm the clocks, then interleave the variants over several rounds so that order,
         # DVFS state and neighbours affect every variant alike; report median and best
+        def timed(plan, reps):
+            if SETS > 1:
+                return plan.time_rotating(d_ins, frames, d_outs, reps)
+            return plan.time_device(d_in, frames, d_out, reps)
+
         for _, plan in plans:
-            plan.time_device(d_in, frames, d_out, 20)
+            timed(plan, 20)
         times = {var: [] for var, _ in plans}
         rels = {}
         for rnd in range(ROUNDS):
             order = plans if rnd % 2 == 0 else plans[::-1]
             for var, plan in order:
-                times[var].append(plan.time_device(d_in, frames, d_out, 10))
-                if rnd == 0:
+                times[var].append(timed(plan, 10 if SETS == 1 else 10 * SETS))
+                if rnd == 0 and MODE == 0:
                     got = np.empty((3, n), np.float32)
                     fsea._check(L.fsea_copy_to_host(0, got.ctypes.data, d_out, got.nbytes))
                     rels[var] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
         for var, plan in plans:
             ms = float(np.median(times[var]))
             best = float(np.min(times[var]))
-            rel = rels[var]
-            gbs = 6.0 * n * frames / (ms * 1e-3) / 1e9
+            rel = rels.get(var, float("nan"))
+            gbs = (2.0 + OUT_BYTES) * n * frames / (ms * 1e-3) / 1e9
             grid = plan.grid(frames)
             print("N=%-5d variant=%-11s %-28s grid=%-4d wg=%-3d lds=%-6d median %7.3f ms (best %7.3f)  %7.1f Mframes/s  "
                   "%6.1f GB/s  %4.1f%% of 8 TB/s  rel=%.1e %s"
                   % (n, var or "-", plan.kernel_name, grid[0], grid[1], grid[2], ms, best, frames / ms / 1e3, gbs,
                      gbs / 80.0, rel,
-                     "OK" if rel < 1e-6 else ("ablation" if var.startswith("abl_") else "MISMATCH")))
+                     "OK" if rel < 1e-6 else ("ablation" if var.startswith("abl_") else ("-" if MODE else "MISMATCH"))))
             plan.close()
 
 

@@ -394,7 +394,11 @@ def test_mean_magnitude_gate_and_composite():
     for k, t in enumerate(tiles):
         O.composite_max(want_img, t, k * (n // 2))
         d_t = DeviceBuffer(t.nbytes).upload(t)
-        fsea.composite_max_device(d_img.ptr, d_t.ptr, k * (n // 2), 0, n, 64, width, n)
+        fsea.composite_max_device(d_img.ptr, d_t.ptr, k * (n // 2), 0, n, 64, width, 64, n)
+        with pytest.raises(fsea.FseaError, match="do not fit"):          # a tile reaching past the last row
+            fsea.composite_max_device(d_img.ptr, d_t.ptr, 0, 1, n, 64, width, 64, n)
+        with pytest.raises(fsea.FseaError, match="row stride"):          # or past the row, without 32-bit wrap-around
+            fsea.composite_max_device(d_img.ptr, d_t.ptr, 0xFFFFFF00, 0, n, 64, width, 64, n)
         d_t.free()                                      # hipFree synchronises the device
     got_img = d_img.download(np.uint8, want_img.shape)
     assert np.array_equal(got_img, want_img)

@@ -268,7 +268,8 @@ def test_imgaxis_exports():
     import re
     text = open(os.path.join(ROOT, "include", "imgaxis.h")).read()
     names = re.findall(r"^(?:int|void)\s+(\w+)\(", text, flags=re.M)
-    assert sorted(names) == ["img_draw_frequency_axis", "img_draw_text", "img_hline", "img_pixel_put", "img_vline"]
+    assert sorted(names) == ["img_draw_broad_markers", "img_draw_frequency_axis", "img_draw_text", "img_hline",
+                             "img_pixel_put", "img_vline"]
     for name in names:
         assert hasattr(nrf.nrf_lib(), name), name
 
@@ -307,6 +308,73 @@ def test_axis_labels_sit_at_the_major_ticks():
     # "1800.00" starts with the glyph of '1': its 5x7 cell (scaled by 6) has the stem in column 2
     cell = 48 // 7
     assert extra[markers_y + 3 * cell, 102 + 2 * cell]
+
+
+class _MarkersCfg(ctypes.Structure):
+    _fields_ = [("source_height", ctypes.c_uint32), ("header_height", ctypes.c_uint32), ("footer_height", ctypes.c_uint32),
+                ("footer_bleed", ctypes.c_uint32), ("sample_rate", ctypes.c_uint32), ("frequency_start", ctypes.c_uint64),
+                ("frequency_end", ctypes.c_uint64), ("minor_tick_rate", ctypes.c_uint32),
+                ("minor_tick_height", ctypes.c_uint32), ("major_tick_rate", ctypes.c_uint32),
+                ("major_tick_height", ctypes.c_uint32), ("font_size_px", ctypes.c_uint32), ("line_color", ctypes.c_uint8)]
+
+
+@pytest.mark.parametrize("width,rows_,start,end,major", [
+    (256 * 21, 200, 600000000, 700000000, 50000000),       # 21 tiles of 5 MHz: two 50 MHz labels inside
+    (23693, 64, 50000000, 6000000000, 50000000),           # the reference poster's width and frequency range
+    (256, 40, 100000000, 100000000, 1000000),              # a single tile
+])
+def test_broad_markers_match_the_restatement(width, rows_, start, end, major):
+    """include/imgaxis.h img_draw_broad_markers vs the numpy restatement of c/add-markers.c:136-230."""
+    L = nrf.nrf_lib()
+    L.img_draw_broad_markers.restype = ctypes.c_int
+    L.img_draw_broad_markers.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_MarkersCfg)]
+    src = np.random.default_rng(width).integers(0, 200, (rows_, width), dtype=np.uint8)
+    want, labels = O.broad_markers(src, 300, 300, start, end, major_tick_rate=major)
+    got = np.zeros_like(want)
+    got[300:300 + rows_] = src
+    cfg = _MarkersCfg(rows_, 300, 300, 35, 5000000, start, end, 1000000, 30, major, 60, 0, 255)
+    n = L.img_draw_broad_markers(got.ctypes.data, width, ctypes.byref(cfg))
+    assert np.array_equal(got, want)
+    assert n == len(labels)
+    assert np.array_equal(got[301:300 + rows_], src[1:])              # the image rows below the border line are untouched
+    assert got[291:301, 1:].min() == 255 and got[300 + rows_: 310 + rows_, 1:].min() == 255     # ten border lines each
+    # with labels: only pixels inside the label band change, all to the line colour
+    cfg.font_size_px = 64
+    text = got.copy()
+    L.img_draw_broad_markers(text.ctypes.data, width, ctypes.byref(cfg))
+    extra = text != got
+    if labels:
+        ys, xs = np.nonzero(extra)
+        assert extra.any() and ys.min() >= labels[0][1] and ys.max() < labels[0][1] + 64 and xs.min() >= labels[0][0]
+    else:
+        assert not extra.any()
+
+
+def test_add_markers_tool_end_to_end(tmp_path):
+    """fsea-add-markers (c/add-markers.c main): broad-stitched-S-E.png -> broad-stitched-S-E-markers.png."""
+    import subprocess
+    L = nrf.nrf_lib()
+    L.write_gray_png.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.read_gray_png.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    src = np.random.default_rng(3).integers(0, 255, (77, 256 * 11), dtype=np.uint8)
+    assert L.write_gray_png(str(tmp_path / "broad-stitched-630-680.png").encode(), src.shape[1], src.shape[0],
+                            src.ctypes.data) == 0
+    tool = os.path.join(ROOT, "frequensea_amd", "bin", "fsea-add-markers")
+    out = subprocess.run([tool, "--start", "630", "--end", "680", "--dir", str(tmp_path)], capture_output=True, text=True,
+                         check=True).stdout
+    assert "Adding markers..." in out
+    w, h = ctypes.c_int(0), ctypes.c_int(0)
+    L.read_gray_png.restype = ctypes.POINTER(ctypes.c_uint8)
+    p = L.read_gray_png(str(tmp_path / "broad-stitched-630-680-markers.png").encode(), ctypes.byref(w), ctypes.byref(h))
+    got = np.ctypeslib.as_array(p, shape=(h.value, w.value)).copy()
+    want, labels = O.broad_markers(src, 300, 300, 630000000, 680000000)
+    assert got.shape == want.shape == (677, 2816)
+    band = np.zeros(got.shape, bool)
+    for x, y, _ in labels:
+        band[y:y + 64, x:] = True
+    assert labels == [(1152, 300 + 77 + 101, "650.00")]               # (650 - 627.5) / 55 MHz * 2816 px
+    assert np.array_equal(got[~band], want[~band]) and (got[band] != want[band]).any()
+    assert subprocess.run([tool, "--start", "1", "--end", "2", "--dir", str(tmp_path)], capture_output=True).returncode != 0
 
 
 def test_dot_matrix_text_advance_and_clipping():
