@@ -67,6 +67,9 @@
 #define FSEA_CFG_8192_NOFLOP 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4, 30
 #define FSEA_CFG_8192_IO 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6, 30
 #define FSEA_CFG_8192_VALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 3, 30
+#define FSEA_CFG_8192_IONT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6, 36894
+#define FSEA_CFG_8192_NOLDSNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 2, 36894
+#define FSEA_CFG_8192_NOFLOPNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4, 36894
 #define FSEA_CFG_8192_NOLOAD 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 64, 30
 #define FSEA_CFG_8192_NOMAG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 128, 30
 // schedule options of the defaults switched off (FftCfg::OPT), for A/B timing in one process
