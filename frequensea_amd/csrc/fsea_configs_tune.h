@@ -28,14 +28,14 @@
 #define FSEA_CFG_8192_LDNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 32926
 #define FSEA_CFG_16384_CP0 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 136
 #define FSEA_CFG_16384_STNT 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 4232
-#define FSEA_CFG_4096_CP0 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 10
-#define FSEA_CFG_4096_STNT 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 4106
+#define FSEA_CFG_4096_CP0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 158
+#define FSEA_CFG_4096_STNT 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 4254
 #define FSEA_CFG_2048_CP0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 14
 #define FSEA_CFG_2048_STNT 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 4110
 #define FSEA_CFG_1024_CP0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 10
 #define FSEA_CFG_1024_LDSTNT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 36874
-#define FSEA_CFG_256_CP0 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true, 0, 0
-#define FSEA_CFG_256_LDSTNT 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true, 0, 36864
+#define FSEA_CFG_256_CP0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 0
+#define FSEA_CFG_256_LDSTNT 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 36864
 // V2 schedule (OPT 64): first exchange inside each wavefront, two barriers per frame; with its
 // measurement-only ablations (8: static units + early prefetch, 16: V1 load mapping, wrong results,
 // 32: no first exchange, wrong results)
@@ -56,6 +56,15 @@
 #define FSEA_CFG_4096_B 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true
 #define FSEA_CFG_4096_C 4096, 128, 2, 2, 3, 16, 8, 32, 1, true, true
 #define FSEA_CFG_4096_D 4096, 128, 2, 2, 3, 8, 16, 32, 1, true, true
+// small sizes with 16 points per lane (2-byte pass-0 loads), as in round 1 and round 2a
+#define FSEA_CFG_256_P16 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true, 0, 4096
+#define FSEA_CFG_128_P16 128, 8, 32, 2, 2, 16, 8, 1, 1, true, true, 0, 4096
+// 4096 as in rounds 1 and 2a: 256 lanes x 16 points, four workgroups per CU (with and without the streaming policy);
+// "B" is the 128-lane layout without round 2's options, "B3" the product layout without deferred twiddles
+#define FSEA_CFG_4096_R1 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 266
+#define FSEA_CFG_4096_T256 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 36874
+#define FSEA_CFG_4096_F1 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, 37022
+#define FSEA_CFG_4096_B3 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 36894
 #define FSEA_CFG_16384_B 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true
 #define FSEA_CFG_2048_B 2048, 64, 4, 2, 3, 8, 8, 32, 1, true, true
 #define FSEA_CFG_2048_C 2048, 64, 4, 2, 3, 4, 16, 32, 1, true, true
@@ -75,6 +84,6 @@
 // schedule options of the defaults switched off (FftCfg::OPT), for A/B timing in one process
 #define FSEA_CFG_8192_X0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 0
 #define FSEA_CFG_8192_X7 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 7
-#define FSEA_CFG_4096_X0 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 0
+#define FSEA_CFG_4096_X0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 0
 #define FSEA_CFG_2048_X0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 0
 #define FSEA_CFG_1024_X0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 0

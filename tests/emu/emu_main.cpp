@@ -148,6 +148,12 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
         EMU_VARIANT(4096, "x0", FSEA_CFG_4096_X0)
         EMU_VARIANT(4096, "df", FSEA_CFG_4096_DF)
         EMU_VARIANT(4096, "B", FSEA_CFG_4096_B)
+        EMU_VARIANT(256, "p16", FSEA_CFG_256_P16)
+        EMU_VARIANT(128, "p16", FSEA_CFG_128_P16)
+        EMU_VARIANT(4096, "f1", FSEA_CFG_4096_F1)
+        EMU_VARIANT(4096, "r1", FSEA_CFG_4096_R1)
+        EMU_VARIANT(4096, "t256", FSEA_CFG_4096_T256)
+        EMU_VARIANT(4096, "B3", FSEA_CFG_4096_B3)
         EMU_VARIANT(4096, "C", FSEA_CFG_4096_C)
         EMU_VARIANT(4096, "D", FSEA_CFG_4096_D)
         EMU_VARIANT(2048, "x0", FSEA_CFG_2048_X0)
