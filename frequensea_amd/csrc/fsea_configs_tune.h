@@ -44,6 +44,9 @@
 #define FSEA_CFG_8192_V2L 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 16, 74
 #define FSEA_CFG_8192_V2SL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 24, 74
 #define FSEA_CFG_8192_V2NA 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 32, 74
+// other pass orders with round 2's options: 16 x 32 x 16 (8-byte row stores), 8 x 32 x 32 (8-byte loads)
+#define FSEA_CFG_8192_B2 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 37022
+#define FSEA_CFG_8192_D2 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 37022
 // other pass orders / twiddle sources
 #define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true
 #define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
