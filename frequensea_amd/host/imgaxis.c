@@ -109,8 +109,13 @@ int img_draw_frequency_axis(uint8_t *buffer, uint32_t image_width, uint32_t imag
                 if (cfg->font_size_px > 0) {
                     char text[64];
                     snprintf(text, sizeof(text), "%.2f", (double)freq / 1e6);
-                    img_draw_text(buffer, image_width, image_height, text, (int)x, (int)markers_y,
-                                  (int)cfg->font_size_px, cfg->line_color);
+                    if (cfg->font != NULL) {
+                        ntt_font_draw(cfg->font, buffer, image_width, image_height, text, (int)x, (int)markers_y,
+                                      (int)cfg->font_size_px);
+                    } else {
+                        img_draw_text(buffer, image_width, image_height, text, (int)x, (int)markers_y,
+                                      (int)cfg->font_size_px, cfg->line_color);
+                    }
                 }
                 labelled++;
             }
@@ -174,8 +179,13 @@ int img_draw_broad_markers(uint8_t *buffer, uint32_t image_width, const img_mark
                     if (cfg->font_size_px > 0) {
                         char text[64];
                         snprintf(text, sizeof(text), "%.2f", (double)freq / 1e6);
-                        img_draw_text(buffer, image_width, out_height, text, x, (int)labels_y, (int)cfg->font_size_px,
-                                      cfg->line_color);
+                        if (cfg->font != NULL) {
+                            ntt_font_draw(cfg->font, buffer, image_width, out_height, text, x, (int)labels_y,
+                                          (int)cfg->font_size_px);
+                        } else {
+                            img_draw_text(buffer, image_width, out_height, text, x, (int)labels_y, (int)cfg->font_size_px,
+                                          cfg->line_color);
+                        }
                     }
                     labelled++;
                 }

@@ -9,6 +9,7 @@
  * file has.  Host-only: no GPU work in this step.
  *
  * usage: fsea-add-markers --start MHZ --end MHZ [--dir DIR] [--header H] [--footer F] [--major MHZ] [--minor MHZ]
+ *                         [--font FILE.ttf]   (TrueType labels; default: built-in dot-matrix digits)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,7 +21,7 @@
 int main(int argc, char **argv) {
     double start = -1, end = -1, major = 50.0, minor = 1.0;
     int header = 300, footer = 300;
-    const char *dir = ".";
+    const char *dir = ".", *font_file = NULL;
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--start") == 0 && i + 1 < argc) start = atof(argv[++i]);
         else if (strcmp(argv[i], "--end") == 0 && i + 1 < argc) end = atof(argv[++i]);
@@ -29,10 +30,11 @@ int main(int argc, char **argv) {
         else if (strcmp(argv[i], "--footer") == 0 && i + 1 < argc) footer = atoi(argv[++i]);
         else if (strcmp(argv[i], "--major") == 0 && i + 1 < argc) major = atof(argv[++i]);
         else if (strcmp(argv[i], "--minor") == 0 && i + 1 < argc) minor = atof(argv[++i]);
+        else if (strcmp(argv[i], "--font") == 0 && i + 1 < argc) font_file = argv[++i];
     }
     if (start < 0 || end < start || header < 10 || footer < 120 || !(major > 0) || !(minor > 0)) {
         fprintf(stderr, "usage: fsea-add-markers --start MHZ --end MHZ [--dir DIR] [--header H>=10] [--footer F>=120] "
-                        "[--major MHZ] [--minor MHZ]\n");
+                        "[--major MHZ] [--minor MHZ] [--font FILE.ttf]\n");
         return EXIT_FAILURE;
     }
     printf("Frequency range: %.0f MHz - %.0f MHz\n", start, end);
@@ -69,7 +71,12 @@ int main(int argc, char **argv) {
     cfg.major_tick_height = 60;
     cfg.font_size_px = 64;
     cfg.line_color = 255;
+    /* FONT_FILE "../fonts/RobotoCondensed-Bold.ttf" in the reference (c/add-markers.c:168): the caller's file here */
+    ntt_font *font = font_file ? ntt_font_load(font_file) : NULL;
+    if (font_file && !font) return EXIT_FAILURE;
+    cfg.font = font;
     img_draw_broad_markers(out, (uint32_t)width, &cfg);
+    ntt_font_free(font);
     printf("Writing %s...\n", out_name);
     if (write_gray_png(out_name, width, out_height, out) != 0) return EXIT_FAILURE;
     free(in);

@@ -6,9 +6,10 @@
  *   WIDTH_STEP = FFT_SIZE / (SAMPLE_RATE / FREQUENCY_STEP)  (integer division, as the reference),
  *   IMAGE_WIDTH = FFT_SIZE + FREQUENCY_RANGE * WIDTH_STEP.
  * With --footer F the image gets F extra rows carrying the frequency ruler of c/fft-stitch.c:191-217
- * (banner lines, 0.1 MHz and 1 MHz ticks, "%.2f" MHz labels; include/imgaxis.h -- the labels use a
- * built-in dot-matrix font, not the reference's TrueType face).  The reference's fixed layout is
- * --rows 11211 --footer 600.
+ * (banner lines, 0.1 MHz and 1 MHz ticks, "%.2f" MHz labels; include/imgaxis.h).  --font FILE.ttf draws
+ * the labels from a TrueType file as the reference does from ../fonts/RobotoCondensed-Regular.ttf
+ * (c/fft-stitch.c:33); without it they are built-in dot-matrix digits.  The reference's fixed layout is
+ * --rows 11211 --footer 600 --font <Roboto>.
  *
  * usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--footer F] [--dir DIR]
  *                        [--device D]
@@ -29,7 +30,7 @@ static void die(const char *what) {
 int main(int argc, char **argv) {
     int broad = 0, device = 0, rows = -1, footer = 0;
     double start = -1, end = -1, step = -1;
-    const char *dir = ".";
+    const char *dir = ".", *font_file = NULL;
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--broad") == 0) broad = 1;
         else if (strcmp(argv[i], "--start") == 0 && i + 1 < argc) start = atof(argv[++i]);
@@ -39,9 +40,10 @@ int main(int argc, char **argv) {
         else if (strcmp(argv[i], "--footer") == 0 && i + 1 < argc) footer = atoi(argv[++i]);
         else if (strcmp(argv[i], "--dir") == 0 && i + 1 < argc) dir = argv[++i];
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--font") == 0 && i + 1 < argc) font_file = argv[++i];
     }
     if (start < 0 || end < start) {
-        fprintf(stderr, "usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--dir DIR]\n");
+        fprintf(stderr, "usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--dir DIR] [--footer ROWS [--font FILE.ttf]]\n");
         return EXIT_FAILURE;
     }
     const uint32_t fft_size = broad ? 256 : 1024;
@@ -116,7 +118,12 @@ int main(int argc, char **argv) {
         axis.major_tick_rate = 1000000;
         axis.font_size_px = 48;
         axis.line_color = 255;
+        /* FONT_FILE "../fonts/RobotoCondensed-Regular.ttf" in the reference (c/fft-stitch.c:38): the caller's file here */
+        ntt_font *font = font_file ? ntt_font_load(font_file) : NULL;
+        if (font_file && !font) return EXIT_FAILURE;
+        axis.font = font;
         img_draw_frequency_axis(image, image_width, full_height, &axis);
+        ntt_font_free(font);
     }
     char out_name[512];
     if (broad) snprintf(out_name, sizeof(out_name), "%s/broad-stitched-%.0f-%.0f.png", dir, start, end);

@@ -5,16 +5,18 @@
  * stitch tool, restated as a small library so that it can be tested without a GPU):
  *   c/fft-stitch.c:56-72     img_pixel_put / img_vline / img_hline
  *   c/fft-stitch.c:191-217   banner lines, minor + major ticks, one "%.2f" MHz label per major tick
- * Labels: the reference rasterises RobotoCondensed-Regular.ttf with stb_truetype (a vendored
- * third-party rasteriser and a font file, neither of which is re-shipped here); this build draws
- * the same strings at the same anchor with a built-in 5x7 dot-matrix digit font scaled to the
- * requested pixel height.  Lines and ticks are pixel-identical to the reference's; label glyph
- * shapes are not.
+ * Labels: the reference rasterises RobotoCondensed-Regular.ttf with stb_truetype.  With a font loaded
+ * (ntt_font_load, include/ntt_font.h; the file is the user's, none is shipped) the same strings are
+ * drawn by this repository's own TrueType rasteriser with the reference's positioning (centred on the
+ * tick, baseline from the font's ascent); without one, a built-in 5x7 dot-matrix digit font scaled to
+ * the requested pixel height is used.  Lines and ticks are pixel-identical to the reference's.
  */
 #ifndef FSEA_IMGAXIS_H
 #define FSEA_IMGAXIS_H
 
 #include <stdint.h>
+
+#include "ntt_font.h"
 
 /* One pixel; like the reference, column 0 and row 0 are never written (its guard is
  * `x > 0 && y > 0`, c/fft-stitch.c:56-60).  Additionally clipped to the image. */
@@ -35,6 +37,8 @@ typedef struct {
     uint32_t major_tick_rate;  /* 1e6 */
     uint32_t font_size_px;     /* 48; 0 = no labels */
     uint8_t line_color;        /* 255 */
+    const ntt_font *font;      /* labels drawn with ntt_font_draw, centred on the tick as the reference does
+                                * (c/fft-stitch.c:214); NULL = the built-in dot-matrix digits, left-aligned */
 } img_axis_config;
 
 /* Draws the ruler of c/fft-stitch.c:191-217 into rows [cfg->rows, image_height) of
@@ -64,6 +68,7 @@ typedef struct {
     uint32_t major_tick_height;/* 60 */
     uint32_t font_size_px;     /* 64; 0 = no labels */
     uint8_t line_color;        /* 255 */
+    const ntt_font *font;      /* as in img_axis_config (c/add-markers.c:227) */
 } img_markers_config;
 
 /* Draws borders, ticks and labels into buffer[header + source + footer][image_width] (the stitched image

@@ -17,4 +17,4 @@ gcc -std=c99 $SAN -I"$R/include" -shared -o "$R/frequensea_amd/libfsea_nrf.so" "
 cd "$R"
 ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) \
-    python -m pytest tests/test_oracle.py tests/test_host_api.py tests/test_reference_tools.py -x -q -p no:cacheprovider
+    python -m pytest tests/test_oracle.py tests/test_host_api.py tests/test_ntt_font.py tests/test_reference_tools.py -x -q -p no:cacheprovider

@@ -85,7 +85,7 @@ def test_narrow_sweep_overlapping_stitch(tmp_path):
     assert img.shape == want.shape and np.array_equal(img, want)
 
     # the same stitch with the reference's 600-row footer: spectrogram rows unchanged, ruler below
-    # (c/fft-stitch.c:191-217); labels are dot-matrix glyphs, everything else equals the restatement
+    # (c/fft-stitch.c:191-217); labels are dot-matrix glyphs without --font, everything else equals the restatement
     subprocess.run([os.path.join(BIN, "fsea-fft-stitch"), "--start", "1802", "--end", "1806", "--footer", "600",
                     "--dir", str(tmp_path)], capture_output=True, text=True, check=True)
     img = _png(tmp_path / "fft-stitched-1802.0000-1806.0000.png")

@@ -251,7 +251,7 @@ class _AxisCfg(ctypes.Structure):
                 ("frequency_step", ctypes.c_uint32), ("frequency_start", ctypes.c_uint64),
                 ("frequency_end", ctypes.c_uint64), ("minor_tick_rate", ctypes.c_uint32),
                 ("major_tick_rate", ctypes.c_uint32), ("font_size_px", ctypes.c_uint32),
-                ("line_color", ctypes.c_uint8)]
+                ("line_color", ctypes.c_uint8), ("font", ctypes.c_void_p)]
 
 
 def _draw_axis(width, height, rows_, start, end, font_px, fft_size=1024, step=2000000):
@@ -270,6 +270,11 @@ def test_imgaxis_exports():
     names = re.findall(r"^(?:int|void)\s+(\w+)\(", text, flags=re.M)
     assert sorted(names) == ["img_draw_broad_markers", "img_draw_frequency_axis", "img_draw_text", "img_hline",
                              "img_pixel_put", "img_vline"]
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ntt_font.h")).read(), flags=re.S)
+    font_names = set(re.findall(r"\b(ntt_font_[a-z_]+)\s*\(", text))
+    assert {"ntt_font_load", "ntt_font_free", "ntt_font_measure", "ntt_font_draw", "ntt_font_glyph_bitmap"} <= font_names
+    for name in font_names:
+        assert hasattr(nrf.nrf_lib(), name), name
     for name in names:
         assert hasattr(nrf.nrf_lib(), name), name
 
@@ -315,7 +320,8 @@ class _MarkersCfg(ctypes.Structure):
                 ("footer_bleed", ctypes.c_uint32), ("sample_rate", ctypes.c_uint32), ("frequency_start", ctypes.c_uint64),
                 ("frequency_end", ctypes.c_uint64), ("minor_tick_rate", ctypes.c_uint32),
                 ("minor_tick_height", ctypes.c_uint32), ("major_tick_rate", ctypes.c_uint32),
-                ("major_tick_height", ctypes.c_uint32), ("font_size_px", ctypes.c_uint32), ("line_color", ctypes.c_uint8)]
+                ("major_tick_height", ctypes.c_uint32), ("font_size_px", ctypes.c_uint32), ("line_color", ctypes.c_uint8),
+                ("font", ctypes.c_void_p)]
 
 
 @pytest.mark.parametrize("width,rows_,start,end,major", [
