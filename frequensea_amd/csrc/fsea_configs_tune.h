@@ -47,6 +47,9 @@
 // other pass orders with round 2's options: 16 x 32 x 16 (8-byte row stores), 8 x 32 x 32 (8-byte loads)
 #define FSEA_CFG_8192_B2 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 37022
 #define FSEA_CFG_8192_D2 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 37022
+// 32 x 32 x 8: four adjacent bins per lane in the last pass (16-byte row stores), 2-byte pass-0 loads; with and without nt loads
+#define FSEA_CFG_8192_W 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, 37022
+#define FSEA_CFG_8192_W2 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, 4254
 // other pass orders / twiddle sources
 #define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true
 #define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
@@ -83,6 +86,14 @@
 #define FSEA_CFG_8192_NOLDSNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 2, 36894
 #define FSEA_CFG_8192_NOFLOPNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4, 36894
 #define FSEA_CFG_8192_NOLOAD 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 64, 30
+// 256 = the row stored 16 bytes per lane (bins misplaced), 512 = the frame loaded 16 bytes per lane (samples
+// misplaced): what layouts with 4 adjacent bins / 8 adjacent samples per lane would issue, without their other costs
+#define FSEA_CFG_8192_IONT_WS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 262, 36894
+#define FSEA_CFG_8192_IONT_WL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 518, 36894
+#define FSEA_CFG_8192_IONT_WLS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 774, 36894
+#define FSEA_CFG_8192_WS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 256, 37022
+#define FSEA_CFG_8192_WL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 512, 37022
+#define FSEA_CFG_8192_WLS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 768, 37022
 #define FSEA_CFG_8192_NOMAG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 128, 30
 // schedule options of the defaults switched off (FftCfg::OPT), for A/B timing in one process
 #define FSEA_CFG_8192_X0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 0

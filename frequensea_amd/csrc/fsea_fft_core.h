@@ -576,6 +576,17 @@ struct FftKernel {
     // voff: this lane's byte offset inside the unit's window (slot * hop + C0 t samples)
     static __device__ __forceinline__ void load_raw(rsrc_t rs, uint32_t voff, Raw *raw) {
         constexpr int STRIDE = N / R0;
+        // ABL 512 (measurement only, wrong samples per lane): the frame's bytes fetched 16 per lane, 1 KiB
+        // runs per wave instruction -- what a pass-0 layout with 8 adjacent samples per lane would issue
+        if constexpr ((Cfg::ABL & 512) != 0 && IN == IN_U8 && C0 == 2 && R0 % 4 == 0 && FPW == 1) {
+#pragma unroll
+            for (int r = 0; r < R0 / 4; ++r) {
+                const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff * 4u, (uint32_t)(r * 16 * T), LD_AUX);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) raw[4 * r + i].w = q[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < R0; ++r) {
             const uint32_t soff = (uint32_t)(r * STRIDE) * IN_BPS;
@@ -813,6 +824,7 @@ struct FftKernel {
             }
         } else {
             const uint32_t voff = lane_elem * 4u;
+            [[maybe_unused]] float wide[4];
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
                 const uint32_t soff = (uint32_t)(r * NsL) * 4u;
@@ -832,6 +844,12 @@ struct FftKernel {
                 }
                 if constexpr (Cfg::ABL & 1) {
                     if (m[0] == -1.0f) bst<CL>(out, voff, soff, m);  // never true: sqrt >= 0
+                } else if constexpr ((Cfg::ABL & 256) != 0 && CL == 1 && RL % 4 == 0) {
+                    // ABL 256 (measurement only, bins land in the wrong places): the row stored 16 bytes per
+                    // lane, 1 KiB runs per wave instruction -- what a last pass with 4 adjacent bins per lane
+                    // would issue.  The values wait in wide[] until four are there.
+                    wide[r & 3] = m[0];
+                    if ((r & 3) == 3) bst<4, ST_AUX>(out, (lane_elem + 3u * (uint32_t)t) * 4u, (uint32_t)((r >> 2) * 4 * T) * 4u, wide);
                 } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);

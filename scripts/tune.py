@@ -15,9 +15,10 @@ fsea.use_tune_library()
 
 VARIANTS = {
     8192: ["", "cp0", "r1", "nd", "st_nt", "st_sc1", "st_sc0sc1", "st_sc1nt", "ld_nt", "x0", "x7", "tk", "pr", "v2", "v2s",
-           "A", "B", "D", "notwl", "notwr",
+           "A", "B", "D", "B2", "D2", "W", "W2", "notwl", "notwr",
            "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu", "abl_noload", "abl_nomag",
-           "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na"],
+           "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na",
+           "abl_io_nt_ws", "abl_io_nt_wl", "abl_io_nt_wls", "abl_ws", "abl_wl", "abl_wls"],
     1024: ["", "cp0", "ldst_nt", "r1", "x0", "B", "C", "D"],
     4096: ["", "cp0", "st_nt", "r1", "t256", "x0", "df", "B", "B3", "C", "D"],
     32: [""], 64: [""], 128: ["", "p16"], 256: ["", "cp0", "ldst_nt", "p16"], 512: [""], 2048: ["", "cp0", "st_nt", "x0", "df", "B", "C"],
