@@ -33,6 +33,7 @@ extern "C" int fsea_kernels_tune_8192a(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_8192b(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_abl(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_mid(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_px(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_big(fsea::KernelEntry *out, int cap);
 #endif
 
@@ -70,7 +71,7 @@ const std::vector<fsea::KernelEntry> &registry() {
                                                     fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384,
 #ifdef FSEA_TUNE
                                                     fsea_kernels_tune_8192a, fsea_kernels_tune_8192b,
-                                                    fsea_kernels_tune_abl, fsea_kernels_tune_mid, fsea_kernels_tune_big,
+                                                    fsea_kernels_tune_abl, fsea_kernels_tune_px, fsea_kernels_tune_mid, fsea_kernels_tune_big,
 #endif
         };
         for (auto fn : lists) {

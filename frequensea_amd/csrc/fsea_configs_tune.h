@@ -94,6 +94,15 @@
 #define FSEA_CFG_8192_WS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 256, 37022
 #define FSEA_CFG_8192_WL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 512, 37022
 #define FSEA_CFG_8192_WLS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 768, 37022
+// pixel-mode ablations (full kernel sets, so that the compile-time DB5 / DB10 kernels exist): 128 = no logarithm,
+// 1 = no pixel stores, 256 = four pixels per dword store (misplaced), 6 = loads + epilogue only
+#define FSEA_CFG_4096_PXNOLOG 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 128, 37022
+#define FSEA_CFG_4096_PXNOST 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 1, 37022
+#define FSEA_CFG_4096_PXWIDE 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 256, 37022
+#define FSEA_CFG_4096_PXIO 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 6, 36894
+#define FSEA_CFG_4096_PXIOWIDE 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 262, 36894
+#define FSEA_CFG_8192_PXNOLOG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 128, 37022
+#define FSEA_CFG_8192_PXWIDE 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 256, 37022
 #define FSEA_CFG_8192_NOMAG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 128, 30
 // schedule options of the defaults switched off (FftCfg::OPT), for A/B timing in one process
 #define FSEA_CFG_8192_X0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 0

@@ -796,6 +796,7 @@ struct FftKernel {
             // 10*log10(p + 1e-20) * s = (10 s log10(2)) * log2(p + 1e-20)
             const float kdb = (mode == MODE_DB10_U8 ? 100.0f : 50.0f) * 0.30102999566398120f;
             const uint32_t voff = lane_elem;
+            [[maybe_unused]] uint8_t wide_px[4];
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
                 const uint32_t soff = (uint32_t)(r * NsL);
@@ -809,12 +810,22 @@ struct FftKernel {
                     // half an ulp whenever the pixel is not clamped to 0 anyway (p > 1e-13), and for
                     // smaller p -- down to log2(0) = -inf, which the conversion saturates -- the pixel
                     // is 0 either way.  Left out: same pixels, one VALU op less per bin.
-                    const float d = kdb * __builtin_amdgcn_logf(p);
+                    float d = kdb * __builtin_amdgcn_logf(p);
+                    if constexpr (Cfg::ABL & 128) d = kdb * p;  // ABL 128 (measurement only): no logarithm
                     int q = (int)d;  // truncation toward zero, as the C cast in the reference
                     q = q < 0 ? 0 : (q > 255 ? 255 : q);
                     px[c] = (uint8_t)q;
                 }
-                if (patched && r == RL / 2 && t == 0) {
+                if constexpr (Cfg::ABL & 1) {
+                    if (px[0] == 255 && px[CL - 1] == 254 && v[0][0] == -1.0f) bst<CL>(out, voff, soff, px);  // (practically) never
+                } else if constexpr ((Cfg::ABL & 256) != 0 && CL <= 2 && (RL * CL) % 4 == 0) {
+                    // ABL 256 (measurement only, pixels land in the wrong places): four pixels per dword store
+                    constexpr int PER = 4 / CL;  // rows per dword
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) wide_px[(r % PER) * CL + c] = px[c];
+                    if (r % PER == PER - 1)
+                        bst<4, ST_AUX>(out, lane_elem + (uint32_t)((4 - CL) * t), (uint32_t)((r / PER) * 4 * T), wide_px);
+                } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + c, soff, px + c);
                 } else {

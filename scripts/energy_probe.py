@@ -13,6 +13,8 @@ fsea.use_tune_library()
 
 N = int(os.environ.get("ENERGY_N", "8192"))
 TOTAL = 1 << 27
+MODE = int(os.environ.get("ENERGY_MODE", "0"))          # epilogue mode (0 = MAG_F32, 1 = DB10_U8, 2 = DB5_U8_DCFIX, ...)
+OUT_BYTES = {0: 4, 1: 1, 2: 1, 3: 8, 4: 4, 5: 4}[MODE]
 SECONDS = float(os.environ.get("ENERGY_SECONDS", "4"))
 variants = sys.argv[1:] or ["-", "r1", "nd", "abl_io", "abl_nolds", "abl_noflop"]
 L = fsea.hip_lib()
@@ -33,11 +35,12 @@ def smi():
     return (float(w.group(1)) if w else float("nan")), (float(s.group(1)) if s else float("nan"))
 
 
-print("input: %s, N=%d, %d frames per launch (%.0f MiB in + %.0f MiB out)" %
-      ("constant 0x80" if os.environ.get("ENERGY_CONST_INPUT") else "noise-like int8", N, frames, 2 * TOTAL / 2**20, 4 * TOTAL / 2**20))
+print("input: %s, N=%d, mode %d, %d frames per launch (%.0f MiB in + %.0f MiB out)" %
+      ("constant 0x80" if os.environ.get("ENERGY_CONST_INPUT") else "noise-like int8", N, MODE, frames, 2 * TOTAL / 2**20,
+       OUT_BYTES * TOTAL / 2**20))
 print("%-12s %-28s %9s %8s %8s %10s %10s %8s" % ("variant", "kernel", "ms/launch", "W", "sclk MHz", "J/launch", "uJ/frame", "% 8TB/s"))
 for var in variants:
-    plan = fsea.Plan(N, variant="" if var == "-" else var)
+    plan = fsea.Plan(N, variant="" if var == "-" else var, mode=MODE)
     ms_list, stop = [], False
 
     def worker():
@@ -57,5 +60,5 @@ for var in variants:
     w = float(np.nanmedian([a for a, _ in samples]))
     clk = float(np.nanmedian([b for _, b in samples]))
     print("%-12s %-28s %9.4f %8.0f %8.0f %10.4f %10.3f %8.1f" %
-          (var, plan.kernel_name, ms, w, clk, w * ms * 1e-3, w * ms * 1e-3 / frames * 1e6, 6.0 * TOTAL / ms / 1e6 / 80.0))
+          (var, plan.kernel_name, ms, w, clk, w * ms * 1e-3, w * ms * 1e-3 / frames * 1e6, (2.0 + OUT_BYTES) * TOTAL / ms / 1e6 / 80.0))
     plan.close()
