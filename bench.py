@@ -131,10 +131,12 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
         step(warmup + k)
     ev1.record()
     torch.cuda.synchronize()
+    # this rank's own K steps are done: its clock stops here; the closing barrier brackets the region, the
+    # job's time is the MAX over ranks (below), and a collective's own latency is not charged to the steps
+    t1 = time.perf_counter()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    t1 = time.perf_counter()
     wall = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / steps          # events on the launch stream
     if dist is not None:
@@ -238,10 +240,10 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
     for _ in range(steps):
         img = step()
     torch.cuda.synchronize()
+    wall = time.perf_counter() - t0       # own completion (rank 0: everything gathered); MAX over ranks below
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
     # FFT kernel alone on this rank's shard (HIP events on the launch stream)
     if ingest:
         iq.copy_(host_iq)
@@ -342,10 +344,10 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
+    wall = time.perf_counter() - t0       # own completion (rank 0: everything gathered); MAX over ranks below
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     k0.record()
     for _ in range(5):
