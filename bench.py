@@ -215,6 +215,17 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         plan.exec_device(iq.data_ptr() + s0, (b - a) * rows, px.data_ptr() + (a - lo) * rows * n, flip=True, stream=stream)
         return px[a - lo: b - lo]
 
+    def write_tiles(image, a, b):                               # rank 0's own tiles, straight into the stitched image
+        s0 = (a - lo) * tile_bytes
+        if ingest:
+            with torch.cuda.stream(copy_stream):
+                iq[s0:(b - lo) * tile_bytes].copy_(host_iq[s0:(b - lo) * tile_bytes], non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record()
+            compute.wait_event(ready)
+        plan.exec_tiled_device(iq.data_ptr() + s0, (b - a) * rows, image.data_ptr(), image.shape[0], image.shape[1], a * n,
+                               rows, n, flip=True, stream=stream)
+
     def composite(image, tile, x):
         fsea.composite_max_device(image.data_ptr(), tile.data_ptr(), x, 0, n, rows, image.shape[1], image.shape[0], n,
                                   device=dev.index, stream=stream)
@@ -228,7 +239,8 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
 
     def step():
         return sweep.run_sweep(tiles, (rows, n), make_tiles, composite, dist=dist, torch=torch, device=dev,
-                               composite_stack=composite_stack, n_chunks=n_chunks)
+                               composite_stack=composite_stack, n_chunks=n_chunks,
+                               write_tiles=None if args.no_fused_stitch else write_tiles)
 
     for _ in range(max(warmup, 1)):
         img = step()
@@ -265,6 +277,11 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         want = numpy_rows(head, 2, n, n, mode="db5")
         got = img[:2, :n].cpu().numpy()
         check = int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())
+        # the stitched image against the plain tile stack of this rank's shard (same kernel, untiled rows)
+        stack = px.view(hi - lo, rows, n)
+        for k in (0, (hi - lo) // 2, hi - lo - 1):
+            if not torch.equal(img[:, (lo + k) * n:(lo + k + 1) * n], stack[k]):
+                raise SystemExit("bench broad: tile %d of the stitched image differs from the tile stack" % (lo + k))
         if check > 1:
             raise SystemExit("bench broad: stitched pixels differ from the numpy guard by %d" % check)
     frames_total = tiles * rows
@@ -275,7 +292,9 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "broad: 512 centre freqs x 256 frames x 4096-pt, DB5_U8_DCFIX tiles, chunked gather "
-                               "to rank 0 overlapped with the FFT + max-composite",
+                               "to rank 0 overlapped with the FFT; rank 0's own tiles are %s" %
+                               ("stitched by the composite kernel" if args.no_fused_stitch else
+                                "written in place by the FFT kernel (fsea_exec_u8_tiled_device), received ones copied in"),
                    "regime": ("ingest: captures start in pinned host memory, H2D inside the step (one PCIe link per GPU)"
                               if ingest else "resident: captures in HBM when the step starts (gather is xGMI-link-bound)"),
                    "gather_chunks": n_chunks,
@@ -464,6 +483,8 @@ def main():
     ap.add_argument("--stream-frames", type=int, default=32767,
                     help="stft16384stream: frames in the stream (32767 = 2^28 samples, SURVEY 8(d) C5)")
     ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
+    ap.add_argument("--no-fused-stitch", action="store_true",
+                    help="broad: rank 0 stitches its own tiles with the composite kernel instead of writing them in place")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--two-stream", action="store_true",

@@ -317,8 +317,14 @@ unsigned *counter_slot(fsea_plan *p, hipStream_t s) {
     return p->d_ctr + FSEA_CTR_WORDS * p->n_slots++;
 }
 
+// where the rows of a launch go when they are tiles of an image (fsea_exec_u8_tiled_device); rows == 0: contiguous
+struct TileLayout {
+    uint32_t rows = 0, pitch_row = 0, pitch_tile = 0;
+    size_t span = 0;
+};
+
 int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
-           hipStream_t s, double rot_delta = 0.0, double rot_phase0 = 0.0) {
+           hipStream_t s, double rot_delta = 0.0, double rot_phase0 = 0.0, const TileLayout *tiles = nullptr) {
     if (n_frames == 0) return FSEA_OK;
     int kind = pick_kind(in_kind, mode, flip);
     const fsea::KernelEntry *e = p->entry;
@@ -349,6 +355,12 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     a.tw_small = p->d_tw;
     a.tw_def = p->d_tw + p->tw_def_off;
+    if (tiles) {
+        a.tile_rows = tiles->rows;
+        a.pitch_row = tiles->pitch_row;
+        a.pitch_tile = tiles->pitch_tile;
+        a.out_span = tiles->span;
+    }
     e->launch(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
     FSEA_HIP(hipGetLastError());
     return FSEA_OK;
@@ -513,6 +525,40 @@ int fsea_exec_u8_device(fsea_plan *p, const void *d_iq, size_t n_frames, int fli
     FSEA_ON_DEVICE(p->device);
     return launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, d_out,
                   static_cast<hipStream_t>(stream));
+}
+
+int fsea_exec_u8_tiled_device(fsea_plan *p, const void *d_iq, size_t n_frames, int flip, void *d_image,
+                              size_t image_rows, size_t image_stride, size_t first_x, size_t tile_rows, size_t tile_step,
+                              void *stream) {
+    int rc = check_exec_args(p, d_iq, d_image, 16);
+    if (rc) return rc;
+    if (n_frames == 0) return FSEA_OK;
+    const size_t n = (size_t)p->n, esz = fsea_plan_row_bytes(p) / n;
+    const int fpw = p->entry->fpw;
+    if (tile_rows == 0 || tile_rows > image_rows) return fail(FSEA_EINVAL, "tile_rows must be in [1, image_rows]");
+    if (tile_rows % (size_t)fpw != 0) {
+        return fail(FSEA_EINVAL, "tile_rows must be a multiple of %d at fft_size %d (frames per workgroup)", fpw, p->n);
+    }
+    if (n_frames % tile_rows != 0) return fail(FSEA_EINVAL, "n_frames must be whole tiles (a multiple of tile_rows)");
+    if (tile_step < n) return fail(FSEA_EINVAL, "tile_step must be at least fft_size: tiles are written, not max-composited");
+    if ((image_stride | first_x | tile_step) % 4 != 0) {
+        return fail(FSEA_EINVAL, "image_stride, first_x and tile_step must be multiples of 4 elements");
+    }
+    const size_t n_tiles = n_frames / tile_rows;
+    if (first_x + (n_tiles - 1) * tile_step + n > image_stride) return fail(FSEA_EINVAL, "tiles leave the image row");
+    const size_t span = image_rows * image_stride - first_x;
+    if (n_frames > 0xffffffffull || image_stride > 0xffffffffull || tile_step > 0xffffffffull ||
+        ((size_t)(fpw - 1) * image_stride + n) * esz > 0xffffffffull) {
+        return fail(FSEA_EINVAL, "image geometry exceeds the kernel's 32-bit row offsets");
+    }
+    TileLayout t;
+    t.rows = (uint32_t)tile_rows;
+    t.pitch_row = (uint32_t)image_stride;
+    t.pitch_tile = (uint32_t)tile_step;
+    t.span = span;
+    FSEA_ON_DEVICE(p->device);
+    return launch(p, fsea::IN_U8, d_iq, n_frames, flip, p->mode, static_cast<char *>(d_image) + first_x * esz,
+                  static_cast<hipStream_t>(stream), 0.0, 0.0, &t);
 }
 
 namespace {

@@ -316,6 +316,12 @@ struct FftArgs {
     // e^{2 pi i rot_delta r N / R0}, the factor between the pass-0 rows of one lane.
     double rot_delta, rot_phase0;
     cf rot_row[32];
+    // Tiled output (fsea_exec_u8_tiled_device): the launch's frames are `tile_rows`-row tiles of an image;
+    // frame f is written at element (f % tile_rows) * pitch_row + (f / tile_rows) * pitch_tile of `out`
+    // instead of f * N, and `out_span` elements are addressable from `out`.  tile_rows == 0: contiguous rows.
+    // (V1 schedule only; tile_rows is a multiple of FPW, so a unit never straddles tiles.)
+    uint32_t tile_rows = 0, pitch_row = 0, pitch_tile = 0;
+    size_t out_span = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -981,7 +987,13 @@ struct FftKernel {
         const uint32_t xormask = (MODE_T >= 0) ? 0u : a.xormask;
         const uint32_t esz = elem_bytes(mode);
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
-        const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
+        const bool tiled = a.tile_rows != 0;
+        const size_t total_out = (size_t)esz * (tiled ? a.out_span : a.n_frames * (size_t)N);
+        auto row_elem = [&](size_t f) -> size_t {  // element offset of frame f's row (FPW == 1 here)
+            if (!tiled) return f * (size_t)N;
+            const uint32_t k = (uint32_t)f / a.tile_rows, y = (uint32_t)f - k * a.tile_rows;
+            return (size_t)y * a.pitch_row + (size_t)k * a.pitch_tile;
+        };
         // pass 0: lane (b, g) of wave w holds samples n = a N/RA + b RC + (w G + g) C0 + c0
         const int b0 = l % RB, g = l / RB;
         const int n_base = b0 * RC + (w * G + g) * C0;
@@ -1152,7 +1164,7 @@ struct FftKernel {
                 for (int r = 1; r < RL; ++r) v[r] = pk_cmul(v[r], twl[r - 1]);
                 dft_regs<RL, 1>(v);
             }
-            epilogue(mode, buffer_window(a.out, (size_t)esz * u * (size_t)N, total_out), out_elem, v, m);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(u), total_out), out_elem, v, m);
             u = un;
             if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * bidx + 8 + iter] = wall_clock64();
             ++iter;
@@ -1208,10 +1220,17 @@ struct FftKernel {
         const uint32_t xormask = (MODE_T >= 0) ? 0u : a.xormask;
         const uint32_t esz = elem_bytes(mode);
         const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
-        const size_t total_out = (size_t)esz * a.n_frames * (size_t)N;
+        const bool tiled = a.tile_rows != 0;
+        const size_t total_out = (size_t)esz * (tiled ? a.out_span : a.n_frames * (size_t)N);
         const uint32_t in_voff = (uint32_t)IN_BPS * ((uint32_t)slot * (uint32_t)a.hop + (uint32_t)(C0 * t));
         const int tl = pass_lane<LAST>(t);  // this lane's place in the last pass
-        const uint32_t out_elem = (uint32_t)slot * (uint32_t)N + (uint32_t)(CL * tl);
+        const uint32_t out_elem = (uint32_t)slot * (tiled ? a.pitch_row : (uint32_t)N) + (uint32_t)(CL * tl);
+        // element offset of frame f's row
+        auto row_elem = [&](size_t f) -> size_t {
+            if (!tiled) return f * (size_t)N;
+            const uint32_t k = (uint32_t)f / a.tile_rows, y = (uint32_t)f - k * a.tile_rows;
+            return (size_t)y * a.pitch_row + (size_t)k * a.pitch_tile;
+        };
 
         // Prologue: every independent request is issued before the first wait, so that
         // the latencies overlap: the ticket for the second unit, unit 0's bytes (HBM
@@ -1413,7 +1432,7 @@ struct FftKernel {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0, MI>(v + c);
             }
-            epilogue(mode, buffer_window(a.out, (size_t)esz * (u * FPW) * (size_t)N, total_out), out_elem, v, tl);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(u * FPW), total_out), out_elem, v, tl);
             u = un;
             if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * b + 8 + iter] = wall_clock64();
             ++iter;

@@ -22,7 +22,7 @@ _MODE_DTYPE = {
 # Every symbol include/fsea.h declares; tests check the built library exports all of them.
 EXPORTS = [
     "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_reset",
-    "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device",
+    "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device", "fsea_exec_u8_tiled_device",
     "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_exec_u8_shifted_device", "fsea_exec_u8_shifted_host", "fsea_mean_magnitude_u8_device",
     "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
     "fsea_copy_to_host", "fsea_stream_synchronize",
@@ -105,6 +105,7 @@ def hip_lib():
         L.fsea_plan_kernel_name.argtypes = [vp]
         L.fsea_plan_kernel_name.restype = ctypes.c_char_p
         L.fsea_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp]
+        L.fsea_exec_u8_tiled_device.argtypes = [vp, vp, sz, ci, vp, sz, sz, sz, sz, sz, vp]
         L.fsea_exec_u8_host.argtypes = [vp, vp, sz, ci, vp]
         L.fsea_exec_f64_host.argtypes = [vp, vp, sz, vp]
         L.fsea_exec_u8_shifted_device.argtypes = [vp, vp, sz, ci, ctypes.c_double, ctypes.c_double, vp, vp]
@@ -185,6 +186,13 @@ class Plan:
         """Device pointers (ints), asynchronous on `stream` (hipStream_t as int, 0 = null stream)."""
         _check(self._L.fsea_exec_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_out_ptr,
                                            stream or None))
+
+    def exec_tiled_device(self, d_iq_ptr, n_frames, d_image_ptr, image_rows, image_stride, first_x, tile_rows, tile_step,
+                          flip=True, stream=0):
+        """Rows written straight into a stitched image (fsea_exec_u8_tiled_device): frame f = row f % tile_rows of
+        tile f // tile_rows, tile k at columns first_x + k * tile_step."""
+        _check(self._L.fsea_exec_u8_tiled_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_image_ptr, image_rows,
+                                                 image_stride, first_x, tile_rows, tile_step, stream or None))
 
     def reset(self):
         _check(self._L.fsea_plan_reset(self._p))

@@ -56,7 +56,8 @@ def frame_sample_range(f_lo, f_hi, n, hop):
 def gather_chunked(n_items, item_shape, dtype, produce, consume, dist=None, torch=None, device=None, n_chunks=8):
     """Items [0, n_items) are partitioned over the ranks; rank r computes its range chunk by chunk with
     produce(a, b) -> tensor [b - a, *item_shape] of `dtype` on `device`, and rank 0 receives every chunk
-    and calls consume(a, b, tensor) for it (own chunks included), chunk index by chunk index.
+    and calls consume(a, b, tensor) for it (own chunks included), chunk index by chunk index.  On rank 0
+    produce may return None: "these items are already where consume would put them" (written in place).
 
     Returns the number of bytes this rank put on the wire (0 on rank 0)."""
     world = dist.get_world_size() if dist is not None else 1
@@ -96,8 +97,9 @@ def gather_chunked(n_items, item_shape, dtype, produce, consume, dist=None, torc
         if j < len(mine):
             a, b = mine[j]
             t = produce(a, b)
-            assert tuple(t.shape) == (b - a,) + tuple(item_shape) and t.dtype == dtype
-            consume(a, b, t)
+            if t is not None:
+                assert tuple(t.shape) == (b - a,) + tuple(item_shape) and t.dtype == dtype
+                consume(a, b, t)
         reqs, bufs = inbox[j]
         for req in reqs:
             req.wait()
@@ -107,7 +109,7 @@ def gather_chunked(n_items, item_shape, dtype, produce, consume, dist=None, torc
 
 
 def run_sweep(n_tiles, tile_shape, make_tiles, composite, dist=None, torch=None, device=None, width_step=None,
-              composite_stack=None, n_chunks=8):
+              composite_stack=None, n_chunks=8, write_tiles=None):
     """Shard `n_tiles` centre frequencies over the ranks of `dist`, gather the tiles to rank 0 chunk by chunk
     and stitch them as they arrive.
 
@@ -115,23 +117,43 @@ def run_sweep(n_tiles, tile_shape, make_tiles, composite, dist=None, torch=None,
     composite(image, tile, x)   max-composites one [H, N] tile into image[:, x:x+N] (rank 0 only)
     composite_stack(image, stack, count, first_x)   optional: all `count` tiles of a stack at once (tile k
                                 at first_x + k * width_step); used instead of `composite`
+    write_tiles(image, lo, hi)  optional, for sweeps whose tiles do not overlap (width_step >= N): rank 0 computes
+                                its own tiles lo..hi-1 straight into the image (fsea_exec_u8_tiled_device) instead
+                                of make_tiles + composite; received stacks are then copied into place (on the
+                                zeroed image max(0, tile) = tile, c/fft-stitch-broad.c:62-87)
     Returns the stitched [H, W] torch.uint8 image on rank 0, None elsewhere.
     """
     h, n = tile_shape
     width_step = n if width_step is None else width_step
     rank = dist.get_rank() if dist is not None else 0
+    disjoint = write_tiles is not None and width_step >= n
     image = None
     if rank == 0:
-        image = torch.zeros((h, stitched_width(n, n_tiles, width_step)), dtype=torch.uint8, device=device)
+        shape = (h, stitched_width(n, n_tiles, width_step))
+        # disjoint tiles that cover every column: every byte is written exactly once, no zero fill needed
+        image = (torch.empty if (disjoint and width_step == n) else torch.zeros)(shape, dtype=torch.uint8, device=device)
+
+    def produce(a, b):
+        if disjoint and rank == 0:
+            write_tiles(image, a, b)
+            return None
+        return make_tiles(a, b)
 
     def consume(a, b, stack):
+        if disjoint:
+            if width_step == n:                              # [cnt, H, N] -> image[:, a*N : b*N] seen as [H, cnt, N]
+                image[:, a * n: b * n].view(h, b - a, n).copy_(stack.permute(1, 0, 2))
+            else:
+                for k in range(b - a):
+                    image[:, (a + k) * width_step: (a + k) * width_step + n].copy_(stack[k])
+            return
         if composite_stack is not None:
             composite_stack(image, stack, b - a, a * width_step)
             return
         for k in range(b - a):
             composite(image, stack[k], (a + k) * width_step)
 
-    gather_chunked(n_tiles, (h, n), torch.uint8, make_tiles, consume, dist=dist, torch=torch, device=device,
+    gather_chunked(n_tiles, (h, n), torch.uint8, produce, consume, dist=dist, torch=torch, device=device,
                    n_chunks=n_chunks)
     return image
 

@@ -103,6 +103,20 @@ int fsea_plan_fft_size(const fsea_plan *plan);
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
                         void *d_out, void *stream);
 
+/* The same transform with the rows written straight into a stitched image: the launch's frames are
+ * consecutive `tile_rows`-row tiles (frame f = row f % tile_rows of tile f / tile_rows), and tile k lands
+ * at columns [first_x + k*tile_step, ... + fft_size) of rows 0..tile_rows-1 of d_image (image_rows rows of
+ * image_stride elements of the plan's output type).  Tiles are WRITTEN, not max-composited, so tile_step
+ * must be >= fft_size; on a zeroed image that equals img_gray_copy's max() of c/fft-stitch-broad.c:62-87
+ * (WIDTH_STEP == FFT_SIZE there), without the tile stack, the image read and the second pass.  Overlapping
+ * tiles (c/fft-stitch.c, step < fft_size) go through fsea_exec_u8_device + fsea_stitch_tiles_device.
+ * n_frames must be whole tiles; tile_rows a multiple of the size's frames per workgroup (1 for
+ * fft_size >= 8192, 2 at 4096, ... 64 at 32: powers of two up to 64 always work); image_stride, first_x,
+ * tile_step multiples of 4 elements; d_image 16-byte aligned. */
+int fsea_exec_u8_tiled_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip, void *d_image,
+                              size_t image_rows, size_t image_stride, size_t first_x, size_t tile_rows,
+                              size_t tile_step, void *stream);
+
 /* Host-buffer execution: copies through pinned staging, runs, copies back,
  * returns when `out` is complete. */
 int fsea_exec_u8_host(fsea_plan *plan, const uint8_t *iq, size_t n_frames, int flip,

@@ -113,11 +113,26 @@ extern "C" void emu_set_shift(double cycles_per_sample, double phase0_cycles) {
     g_rot_phase0 = phase0_cycles;
 }
 
+// tiled output (FftArgs::tile_rows ...): set before a call, cleared by it
+static uint32_t g_tile_rows = 0, g_pitch_row = 0, g_pitch_tile = 0;
+static size_t g_out_span = 0;
+extern "C" void emu_set_tiles(uint32_t tile_rows, uint32_t pitch_row, uint32_t pitch_tile, size_t out_span) {
+    g_tile_rows = tile_rows;
+    g_pitch_row = pitch_row;
+    g_pitch_tile = pitch_tile;
+    g_out_span = out_span;
+}
+
 extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int specialised, const void *in, void *out,
                                size_t n_frames, size_t hop, int flip, int mode, unsigned grid) {
     fsea::FftArgs a;
     a.rot_delta = g_rot_delta;
     a.rot_phase0 = g_rot_phase0;
+    a.tile_rows = g_tile_rows;
+    a.pitch_row = g_pitch_row;
+    a.pitch_tile = g_pitch_tile;
+    a.out_span = g_out_span;
+    g_tile_rows = 0;
     a.in = in;
     a.out = out;
     a.n_frames = n_frames;

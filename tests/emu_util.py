@@ -59,3 +59,18 @@ def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=T
                                    out.ctypes.data, n_frames, hop, int(bool(flip)), mode, grid)
     assert rc == 0, "emu_fft_variant(%d, %r) = %d" % (n, variant, rc)
     return out
+
+
+def emu_tiled(iq, n, n_frames, image_shape, first_x, tile_rows, tile_step, mode=0, grid=2, specialised=True, variant="",
+              fill=0):
+    """The kernel's tiled-output addressing (fsea_exec_u8_tiled_device): rows written into an image of `image_shape`
+    pre-filled with `fill`."""
+    L = emu_lib()
+    L.emu_set_tiles.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_size_t]
+    image = np.full(image_shape, fill, dtype=OUT_DTYPE[mode])
+    L.emu_set_tiles(tile_rows, image_shape[1], tile_step, image.size - first_x)
+    src = np.ascontiguousarray(iq)
+    rc = L.emu_fft_variant(n, variant.encode(), 0, int(specialised), src.ctypes.data,
+                           image.ctypes.data + first_x * image.itemsize, n_frames, n, 1, mode, grid)
+    assert rc == 0
+    return image

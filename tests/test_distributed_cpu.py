@@ -95,6 +95,61 @@ def test_sweep_gather_and_stitch_over_gloo(tmp_path, world):
     assert np.array_equal(np.load(out), _expected())
 
 
+def _disjoint_worker(rank, world, port, out_path, step):
+    """The fft-batch-broad shape (tiles side by side, WIDTH_STEP >= N): rank 0 writes its own tiles in place."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def make_tiles(lo, hi):
+            assert rank != 0, "rank 0 has write_tiles"
+            return torch.from_numpy(np.stack([_tile(f) for f in range(lo, hi)]))
+
+        def write_tiles(image, lo, hi):
+            calls.append((lo, hi))
+            for f in range(lo, hi):
+                image[:, f * step: f * step + N] = torch.from_numpy(_tile(f))
+
+        def composite(image, tile, x):
+            raise AssertionError("disjoint tiles are copied, not composited")
+
+        img = sweep.run_sweep(TILES, (H, N), make_tiles, composite, dist=dist, torch=torch, device="cpu",
+                              width_step=step, n_chunks=2, write_tiles=write_tiles)
+        if rank == 0:
+            assert calls and calls[0][0] == 0
+            np.save(out_path, img.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,step", [(2, N), (3, N), (2, N + 24)])
+def test_disjoint_sweep_written_in_place_over_gloo(tmp_path, world, step):
+    out = str(tmp_path / "stitched.npy")
+    mp.spawn(_disjoint_worker, args=(world, _free_port(), out, step), nprocs=world, join=True)
+    want = np.zeros((H, sweep.stitched_width(N, TILES, step)), np.uint8)
+    for f in range(TILES):
+        O.composite_max(want, _tile(f), f * step)
+    assert np.array_equal(np.load(out), want)
+
+
+def test_overlapping_sweep_ignores_write_tiles():
+    """write_tiles is only valid for disjoint tiles: with WIDTH_STEP < N the max-composite path runs."""
+    def make_tiles(lo, hi):
+        return torch.from_numpy(np.stack([_tile(f) for f in range(lo, hi)]))
+
+    def composite(image, tile, x):
+        image[:, x:x + N] = torch.maximum(image[:, x:x + N], tile)
+
+    def write_tiles(image, lo, hi):
+        raise AssertionError("not for overlapping tiles")
+
+    img = sweep.run_sweep(TILES, (H, N), make_tiles, composite, dist=None, torch=torch, device="cpu", width_step=STEP,
+                          write_tiles=write_tiles)
+    assert np.array_equal(img.numpy(), _expected())
+
+
 # ---- BASELINE config 5: one overlapped stream, frames sharded with a halo, rows gathered to rank 0 ----
 SN, SHOP, SFRAMES = 512, 256, 23                    # 50 % overlap, a frame count no world size divides
 

@@ -8,7 +8,7 @@ import pytest
 from oracle import oracle as O
 from tests import parity
 from tests.conftest import GOLDEN_KEYS, synth_iq
-from tests.emu_util import emu_rows
+from tests.emu_util import emu_rows, emu_tiled
 
 SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
 
@@ -165,3 +165,20 @@ def test_frequency_shift_overlap_negative_offset_and_no_flip():
     for delta, flip in ((-0.123456789, True), (0.49, False), (0.0, True), (7.25, True)):
         got = emu_rows(iq, n, nf, hop=hop, flip=flip, mode=3, grid=3, shift=(delta, 0.0))
         parity.check_mode_shifted(got, iq, n, nf, hop, flip, 3, delta, 0.0)
+
+
+@pytest.mark.parametrize("n,tile_rows,mode", [(8192, 3, 2), (4096, 4, 2), (4096, 2, 0), (1024, 8, 1), (256, 32, 2), (64, 64, 0)])
+def test_tiled_output_addressing(n, tile_rows, mode):
+    """fsea_exec_u8_tiled_device's addressing in the kernel source: tile k of the launch lands at columns
+    first_x + k * tile_step of rows 0..tile_rows-1, everything else in the image stays as it was."""
+    tiles, first_x, step = 3, 8, n + 12
+    nf = tiles * tile_rows
+    iq = synth_iq(n + tile_rows, 2 * nf * n)
+    rows = emu_rows(iq, n, nf, mode=mode, grid=2)
+    fill = 7
+    shape = (tile_rows + 1, first_x + (tiles - 1) * step + n + 4)
+    image = emu_tiled(iq, n, nf, shape, first_x, tile_rows, step, mode=mode, grid=2, fill=fill)
+    want = np.full(shape, fill, dtype=rows.dtype)
+    for k in range(tiles):
+        want[:tile_rows, first_x + k * step: first_x + k * step + n] = rows[k * tile_rows:(k + 1) * tile_rows]
+    assert np.array_equal(image, want)

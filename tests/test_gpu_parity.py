@@ -175,6 +175,57 @@ def test_compile_time_pixel_kernels(n):
         plan.close()
 
 
+@pytest.mark.parametrize("n,tile_rows,mode", [(8192, 3, 2), (8192, 5, 0), (4096, 6, 2), (4096, 256, 1), (2048, 8, 3), (1024, 16, 2),
+                                              (256, 32, 2), (64, 64, 0), (16384, 2, 2)])
+def test_tiled_exec_writes_the_stitched_image_in_place(n, tile_rows, mode):
+    """fsea_exec_u8_tiled_device: the rows of the launch land as side-by-side tiles of an image and equal, bit for
+    bit, the plain rows of the same plan max-composited by the oracle (c/fft-stitch-broad.c:62-87) onto a zeroed
+    image; bytes outside the tiles (gaps when tile_step > N, the rows below, the margin left of first_x) keep
+    what they held."""
+    tiles, first_x, step = 5, 16, n + 24
+    nf = tiles * tile_rows
+    iq = synth_iq(n + tile_rows, 2 * nf * n)
+    dt = {0: np.float32, 1: np.uint8, 2: np.uint8, 3: np.complex64}[mode]
+    plan = fsea.Plan(n, mode=mode)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_rows = DeviceBuffer(nf * n * np.dtype(dt).itemsize)
+    plan.exec_device(d_in.ptr, nf, d_rows.ptr)
+    plan.synchronize()
+    rows = d_rows.download(dt, (nf, n))
+    shape = (tile_rows + 2, first_x + (tiles - 1) * step + n + 8)
+    fill = np.full(shape, 3, dtype=dt)
+    d_img = DeviceBuffer(fill.nbytes).upload(fill)
+    plan.exec_tiled_device(d_in.ptr, nf, d_img.ptr, shape[0], shape[1], first_x, tile_rows, step)
+    plan.synchronize()
+    got = d_img.download(dt, shape)
+    want = fill.copy()
+    for k in range(tiles):
+        want[:tile_rows, first_x + k * step: first_x + k * step + n] = rows[k * tile_rows:(k + 1) * tile_rows]
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    if mode in (1, 2):                                          # the reference's operation on a zeroed image
+        zero = np.zeros(shape, np.uint8)
+        d_img.upload(zero)
+        plan.exec_tiled_device(d_in.ptr, nf, d_img.ptr, shape[0], shape[1], first_x, tile_rows, step)
+        plan.synchronize()
+        ref = zero.copy()
+        for k in range(tiles):
+            O.composite_max(ref[:tile_rows], np.ascontiguousarray(rows[k * tile_rows:(k + 1) * tile_rows]), first_x + k * step)
+        assert np.array_equal(d_img.download(np.uint8, shape), ref)
+        parity.check_mode(rows, iq, n, nf, n, True, mode)
+    # argument checks: ragged tiles, overlapping tiles, a tile that leaves the row, frames-per-workgroup granularity
+    L = fsea.hip_lib()
+    bad = [(nf - 1, shape[0], shape[1], first_x, tile_rows, step), (nf, shape[0], shape[1], first_x, tile_rows, n - 4),
+           (nf, shape[0], shape[1], first_x + 64, tile_rows, step), (nf, tile_rows - 1, shape[1], first_x, tile_rows, step),
+           (nf, shape[0], shape[1], first_x + 1, tile_rows, step)]
+    for frames, ir, st, fx, tr, ts in bad:
+        assert L.fsea_exec_u8_tiled_device(plan._p, d_in.ptr, frames, 1, d_img.ptr, ir, st, fx, tr, ts, None) != 0
+    if n == 4096:
+        assert L.fsea_exec_u8_tiled_device(plan._p, d_in.ptr, 5, 1, d_img.ptr, shape[0], shape[1], first_x, 1, step, None) != 0
+    for b in (d_in, d_rows, d_img):
+        b.free()
+    plan.close()
+
+
 def test_device_resident_and_ragged_counts():
     n = 2048
     plan = fsea.Plan(n)
@@ -815,6 +866,17 @@ def test_config_c4_broad_sweep_at_full_size():
             fsea._check(L.fsea_copy_to_host(0, img_row.ctypes.data,
                                             ctypes.c_void_p(d_img.ptr.value + y * tiles * n + k * n), n))
             assert np.array_equal(img_row, tile_row)          # no overlap at step = width: max with 0
+    # the same image written in place by the FFT kernel (no tile stack, no second pass) is the same image
+    d_img2 = DeviceBuffer(rows * tiles * n)
+    plan.exec_tiled_device(d_in.ptr, tiles * rows, d_img2.ptr, rows, tiles * n, 0, rows, n)
+    plan.synchronize()
+    for y in (0, 1, 100, rows - 1):
+        a = np.empty(tiles * n, np.uint8)
+        b2 = np.empty(tiles * n, np.uint8)
+        fsea._check(L.fsea_copy_to_host(0, a.ctypes.data, ctypes.c_void_p(d_img.ptr.value + y * tiles * n), a.nbytes))
+        fsea._check(L.fsea_copy_to_host(0, b2.ctypes.data, ctypes.c_void_p(d_img2.ptr.value + y * tiles * n), b2.nbytes))
+        assert np.array_equal(a, b2)
+    d_img2.free()
     for b in (d_in, d_px, d_img):
         b.free()
     plan.close()
