@@ -94,6 +94,12 @@
 #define FSEA_CFG_8192_WS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 256, 37022
 #define FSEA_CFG_8192_WL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 512, 37022
 #define FSEA_CFG_8192_WLS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 768, 37022
+// the small sizes without nt stores, as full kernel sets: the pixel kernels' 16- and 32-byte row pieces are merged in L2
+// only when the stores are allowed to stay there
+#define FSEA_CFG_128_ST0 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, 0
+#define FSEA_CFG_256_ST0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 0
+#define FSEA_CFG_512_ST0 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, 0
+#define FSEA_CFG_1024_ST0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 10
 // pixel-mode ablations (full kernel sets, so that the compile-time DB5 / DB10 kernels exist): 128 = no logarithm,
 // 1 = no pixel stores, 256 = four pixels per dword store (misplaced), 6 = loads + epilogue only
 #define FSEA_CFG_4096_PXNOLOG 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 128, 37022

@@ -522,6 +522,14 @@ struct FftKernel {
     // OPT 4096 / 8192 / 16384: cache policy of the f32 row stores (measurement variants): nt (streaming),
     // sc1 (write through the XCD's L2 and drop the line), sc0 sc1
     static constexpr int ST_AUX = ((Cfg::OPT & 4096) ? 2 : 0) | ((Cfg::OPT & 8192) ? 16 : 0) | ((Cfg::OPT & 16384) ? 1 : 0);
+    // One store instruction writes, per frame, the T lanes' CL adjacent elements: T*CL*size bytes in a row.  A
+    // streaming (nt) store of less than a 128-byte line reaches HBM as a partial line -- measured write traffic
+    // (WRITE_SIZE) of the u8 pixel rows 1.2x (1024 points, 32-byte pieces) to 2.4x (128 points, 16-byte pieces) the
+    // row bytes, f32 rows in 64-byte pieces 1.04x -- while the default policy lets L2 assemble the line from the
+    // neighbouring rows' pieces first: 128-point DB10 pixels 0.205 -> 0.117 ms per 256 MiB of samples.  So only
+    // pieces of a whole line or more are stored nt (profiles/r02_store_policy_by_piece_size.txt).
+    template <int ELEM_BYTES>
+    static constexpr int st_aux() { return (T * CL * ELEM_BYTES >= 128) ? ST_AUX : (ST_AUX & ~2); }
     // OPT 32768: the input loads are streaming (nt) as well
     static constexpr int LD_AUX = (Cfg::OPT & 32768) ? 2 : 0;
     static constexpr bool DEFER = (Cfg::OPT & 128) != 0 && NP == 3;
@@ -796,7 +804,7 @@ struct FftKernel {
                 cf z[CL];
 #pragma unroll
                 for (int c = 0; c < CL; ++c) z[c] = v[r * CL + c] * cf{SE, SE};
-                bst<CL, ST_AUX>(out, voff, (uint32_t)(r * NsL) * 8u, z);
+                bst<CL, st_aux<8>()>(out, voff, (uint32_t)(r * NsL) * 8u, z);
             }
         } else if (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) {
             // 10*log10(p + 1e-20) * s = (10 s log10(2)) * log2(p + 1e-20)
@@ -835,7 +843,7 @@ struct FftKernel {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + c, soff, px + c);
                 } else {
-                    bst<CL, ST_AUX>(out, voff, soff, px);
+                    bst<CL, st_aux<1>()>(out, voff, soff, px);
                 }
                 if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + CL, soff, px + (CL - 1));
             }
@@ -871,7 +879,7 @@ struct FftKernel {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);
                 } else {
-                    bst<CL, ST_AUX>(out, voff, soff, m);
+                    bst<CL, st_aux<4>()>(out, voff, soff, m);
                 }
                 if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + 4 * CL, soff, m + (CL - 1));
             }
