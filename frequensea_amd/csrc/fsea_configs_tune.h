@@ -71,6 +71,11 @@
 #define FSEA_CFG_4096_T256 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 36874
 #define FSEA_CFG_4096_F1 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, 37022
 #define FSEA_CFG_4096_B3 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 36894
+// lane rotation against LDS read conflicts (OPT 16 = middle pass, 32 = last pass) switched OFF where the product has it:
+// 4096 without the last-pass rotation, 2048 without the middle-pass rotation (scripts/lds_conflicts.py predicts 2 cycles
+// per ds_read_b128 group; measured SQ_LDS_BANK_CONFLICT 4.3 M / 8.5 M cycles per launch against 0.1 M / 4.3 M with it)
+#define FSEA_CFG_4096_LR 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 37022   /* "nr": without the last-pass rotation */
+#define FSEA_CFG_2048_LR 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 36878      /* "nr": without the middle-pass rotation */
 #define FSEA_CFG_16384_B 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true
 #define FSEA_CFG_2048_B 2048, 64, 4, 2, 3, 8, 8, 32, 1, true, true
 #define FSEA_CFG_2048_C 2048, 64, 4, 2, 3, 4, 16, 32, 1, true, true

@@ -107,11 +107,17 @@ def remap(t, rot):
 
 
 def pass_cycles(cfg, i, write, rot=0):
-    """Sum over the waves of one frame of LDS-array cycles for pass i's writes or reads."""
+    """Sum over the waves of one frame (or, for T < 64, of the 64 / T frames that share a wave: frame s of the
+    workgroup lives at s * LDS_FRAME, LDS_FRAME = N + 2 T complex) of LDS-array cycles for pass i's writes or reads."""
     tot = ideal = 0
+    frame = 8 * (cfg.N + 2 * cfg.T)
     for w in range(max(1, cfg.T // 64)):
-        lanes = [remap(64 * w + l, rot) if cfg.T >= 64 else remap((64 * w + l) % cfg.T, rot) for l in range(64)]
-        per_lane = [split(cfg.write_accesses(i, t) if write else cfg.read_accesses(i, t)) for t in lanes]
+        if cfg.T >= 64:
+            lanes = [(remap(64 * w + l, rot), 0) for l in range(64)]
+        else:
+            lanes = [(remap(l % cfg.T, rot) if cfg.T >= 16 else l % cfg.T, (l // cfg.T) * frame) for l in range(64)]
+        per_lane = [[(a + off, nb) for a, nb in split(cfg.write_accesses(i, t) if write else cfg.read_accesses(i, t))]
+                    for t, off in lanes]
         for k in range(len(per_lane[0])):
             c, base = cycles([per_lane[l][k][0] for l in range(64)], per_lane[0][k][1], write)
             tot += c
@@ -119,9 +125,10 @@ def pass_cycles(cfg, i, write, rot=0):
     return tot, ideal
 
 
+# the product configurations (fsea_configs.h): N -> (lanes per frame, radices)
 CONFIGS = {
-    128: (8, [16, 8]), 256: (16, [16, 16]), 512: (16, [32, 16]), 1024: (32, [32, 32]),
-    2048: (64, [16, 16, 8]), 4096: (256, [16, 16, 16]), 8192: (256, [16, 16, 32]), 16384: (512, [16, 32, 32]),
+    32: (4, [8, 4]), 64: (4, [16, 4]), 128: (4, [16, 8]), 256: (8, [16, 16]), 512: (16, [32, 16]), 1024: (32, [32, 32]),
+    2048: (64, [16, 16, 8]), 4096: (128, [16, 16, 16]), 8192: (256, [16, 16, 32]), 16384: (512, [16, 32, 32]),
 }
 
 if __name__ == "__main__":
