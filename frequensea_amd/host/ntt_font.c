@@ -35,17 +35,26 @@ struct ntt_font {
     int ascent, descent, line_gap;
 };
 
-static uint16_t u16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
-static int16_t s16(const uint8_t *p) { return (int16_t)u16(p); }
-static uint32_t u32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+/* Every read of the file image goes through these: an offset past the end reads as zero, so a damaged or
+ * truncated file can make a label wrong but never makes the reader leave its buffer (tests/fuzz, scripts/fuzz_ntt_font.sh). */
+static uint32_t rd8(const ntt_font *f, size_t off) { return off < f->size ? f->data[off] : 0u; }
+static uint32_t rd16(const ntt_font *f, size_t off) {
+    return (off + 2 <= f->size && off + 2 > off) ? (uint32_t)((f->data[off] << 8) | f->data[off + 1]) : 0u;
+}
+static int rds16(const ntt_font *f, size_t off) { return (int16_t)rd16(f, off); }
+static uint32_t rd32(const ntt_font *f, size_t off) {
+    if (off + 4 > f->size || off + 4 < off) return 0u;
+    const uint8_t *p = f->data + off;
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
 
 static uint32_t find_table(const ntt_font *f, const char *tag) {
-    const int n = u16(f->data + 4);
-    for (int i = 0; i < n; i++) {
-        const uint8_t *rec = f->data + 12 + 16 * (size_t)i;
-        if ((size_t)(rec - f->data) + 16 > f->size) return 0;
-        if (memcmp(rec, tag, 4) == 0) {
-            const uint32_t off = u32(rec + 8), len = u32(rec + 12);
+    const uint32_t n = rd16(f, 4);
+    for (uint32_t i = 0; i < n; i++) {
+        const size_t rec = 12 + 16 * (size_t)i;
+        if (rec + 16 > f->size) return 0;
+        if (memcmp(f->data + rec, tag, 4) == 0) {
+            const uint32_t off = rd32(f, rec + 8), len = rd32(f, rec + 12);
             return ((size_t)off + len <= f->size) ? off : 0;
         }
     }
@@ -88,26 +97,32 @@ ntt_font *ntt_font_load(const char *font_file) {
         ntt_font_free(f);
         return NULL;
     }
-    f->num_glyphs = u16(f->data + maxp + 4);
-    f->units_per_em = u16(f->data + f->head + 18);
-    f->loc_format = s16(f->data + f->head + 50);
-    f->ascent = s16(f->data + f->hhea + 4);
-    f->descent = s16(f->data + f->hhea + 6);
-    f->line_gap = s16(f->data + f->hhea + 8);
-    f->num_hmetrics = u16(f->data + f->hhea + 34);
+    f->num_glyphs = (int)rd16(f, (size_t)maxp + 4);
+    f->units_per_em = (int)rd16(f, (size_t)f->head + 18);
+    f->loc_format = rds16(f, (size_t)f->head + 50);
+    f->ascent = rds16(f, (size_t)f->hhea + 4);
+    f->descent = rds16(f, (size_t)f->hhea + 6);
+    f->line_gap = rds16(f, (size_t)f->hhea + 8);
+    f->num_hmetrics = (int)rd16(f, (size_t)f->hhea + 34);
+    if (f->ascent - f->descent <= 0 || f->num_hmetrics < 1) {
+        fprintf(stderr, "ERROR ntt_font_load: %s has unusable vertical / horizontal metrics\n", font_file);
+        ntt_font_free(f);
+        return NULL;
+    }
     /* a Unicode cmap subtable: (3,10) / (0,4+) format 12 first, else (3,1) / (0,x) format 4 */
-    const int n_sub = u16(f->data + f->cmap + 2);
+    const uint32_t n_sub = rd16(f, (size_t)f->cmap + 2);
     for (int pass = 0; pass < 2 && !f->cmap_sub; pass++) {
-        for (int i = 0; i < n_sub; i++) {
-            const uint8_t *rec = f->data + f->cmap + 4 + 8 * (size_t)i;
-            const int platform = u16(rec), encoding = u16(rec + 2);
-            const uint32_t off = f->cmap + u32(rec + 4);
-            if (off + 4 > f->size) continue;
-            const int format = u16(f->data + off);
+        for (uint32_t i = 0; i < n_sub; i++) {
+            const size_t rec = (size_t)f->cmap + 4 + 8 * (size_t)i;
+            if (rec + 8 > f->size) break;
+            const uint32_t platform = rd16(f, rec), encoding = rd16(f, rec + 2);
+            const size_t off = (size_t)f->cmap + rd32(f, rec + 4);
+            if (off + 16 > f->size) continue;
+            const uint32_t format = rd16(f, off);
             const int unicode = (platform == 0) || (platform == 3 && (encoding == 1 || encoding == 10));
             if (unicode && ((pass == 0 && format == 12) || (pass == 1 && format == 4))) {
-                f->cmap_sub = off;
-                f->cmap_format = format;
+                f->cmap_sub = (uint32_t)off;
+                f->cmap_format = (int)format;
                 break;
             }
         }
@@ -127,31 +142,34 @@ void ntt_font_free(ntt_font *font) {
 }
 
 int ntt_font_glyph_index(const ntt_font *f, int codepoint) {
-    const uint8_t *t = f->data + f->cmap_sub;
+    const size_t t = f->cmap_sub;
+    if (codepoint < 0) return 0;
     if (f->cmap_format == 4) {
         if (codepoint > 0xffff) return 0;
-        const int segx2 = u16(t + 6);
-        const uint8_t *end_code = t + 14, *start_code = end_code + segx2 + 2;
-        const uint8_t *id_delta = start_code + segx2, *id_range = id_delta + segx2;
-        for (int i = 0; i < segx2; i += 2) {
-            if (codepoint <= u16(end_code + i)) {
-                const int start = u16(start_code + i);
-                if (codepoint < start) return 0;
-                const int range = u16(id_range + i);
-                if (range == 0) return (codepoint + s16(id_delta + i)) & 0xffff;
-                const uint8_t *g = id_range + i + range + 2 * (codepoint - start);
-                if ((size_t)(g - f->data) + 2 > f->size) return 0;
-                const int glyph = u16(g);
-                return glyph ? (glyph + s16(id_delta + i)) & 0xffff : 0;
+        const size_t segx2 = rd16(f, t + 6) & ~1u;
+        const size_t end_code = t + 14, start_code = end_code + segx2 + 2;
+        const size_t id_delta = start_code + segx2, id_range = id_delta + segx2;
+        for (size_t i = 0; i < segx2; i += 2) {
+            if (end_code + i + 2 > f->size) return 0;
+            if ((uint32_t)codepoint <= rd16(f, end_code + i)) {
+                const uint32_t start = rd16(f, start_code + i);
+                if ((uint32_t)codepoint < start) return 0;
+                const uint32_t range = rd16(f, id_range + i);
+                if (range == 0) return (int)(((uint32_t)codepoint + rd16(f, id_delta + i)) & 0xffffu);
+                const uint32_t glyph = rd16(f, id_range + i + range + 2 * (size_t)((uint32_t)codepoint - start));
+                return glyph ? (int)((glyph + rd16(f, id_delta + i)) & 0xffffu) : 0;
             }
         }
         return 0;
     }
-    const uint32_t n_groups = u32(t + 12);
+    const uint32_t n_groups = rd32(f, t + 12);
     for (uint32_t i = 0; i < n_groups; i++) {
-        const uint8_t *g = t + 16 + 12 * (size_t)i;
-        const uint32_t start = u32(g), end = u32(g + 4);
-        if ((uint32_t)codepoint >= start && (uint32_t)codepoint <= end) return (int)(u32(g + 8) + ((uint32_t)codepoint - start));
+        const size_t g = t + 16 + 12 * (size_t)i;
+        if (g + 12 > f->size) return 0;
+        const uint32_t start = rd32(f, g), end = rd32(f, g + 4);
+        if ((uint32_t)codepoint >= start && (uint32_t)codepoint <= end) {
+            return (int)((rd32(f, g + 8) + ((uint32_t)codepoint - start)) & 0xffffu);
+        }
     }
     return 0;
 }
@@ -167,53 +185,56 @@ void ntt_font_vmetrics(const ntt_font *f, int *ascent, int *descent, int *line_g
 }
 
 void ntt_font_hmetrics(const ntt_font *f, int glyph, int *advance, int *lsb) {
-    const uint8_t *h = f->data + f->hmtx;
+    const size_t h = f->hmtx;
+    if (glyph < 0) glyph = 0;
     if (glyph < f->num_hmetrics) {
-        if (advance) *advance = u16(h + 4 * (size_t)glyph);
-        if (lsb) *lsb = s16(h + 4 * (size_t)glyph + 2);
+        if (advance) *advance = (int)rd16(f, h + 4 * (size_t)glyph);
+        if (lsb) *lsb = rds16(f, h + 4 * (size_t)glyph + 2);
     } else {
-        if (advance) *advance = u16(h + 4 * (size_t)(f->num_hmetrics - 1));
-        if (lsb) *lsb = s16(h + 4 * (size_t)f->num_hmetrics + 2 * (size_t)(glyph - f->num_hmetrics));
+        if (advance) *advance = (int)rd16(f, h + 4 * (size_t)(f->num_hmetrics - 1));
+        if (lsb) *lsb = rds16(f, h + 4 * (size_t)f->num_hmetrics + 2 * (size_t)(glyph - f->num_hmetrics));
     }
 }
 
 int ntt_font_kern_advance(const ntt_font *f, int glyph1, int glyph2) {
     if (!f->kern) return 0;
-    const uint8_t *k = f->data + f->kern;
-    if (u16(k + 2) < 1 || u16(k + 8) != 1) return 0; /* first subtable: horizontal, format 0 */
-    int lo = 0, hi = u16(k + 10) - 1;
-    const uint32_t needle = ((uint32_t)glyph1 << 16) | (uint32_t)glyph2;
+    const size_t k = f->kern;
+    if (rd16(f, k + 2) < 1 || rd16(f, k + 8) != 1) return 0; /* first subtable: horizontal, format 0 */
+    int lo = 0, hi = (int)rd16(f, k + 10) - 1;
+    const uint32_t needle = ((uint32_t)glyph1 << 16) | ((uint32_t)glyph2 & 0xffffu);
     while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
-        const uint32_t key = u32(k + 18 + 6 * (size_t)mid);
+        const uint32_t key = rd32(f, k + 18 + 6 * (size_t)mid);
         if (needle < key) hi = mid - 1;
         else if (needle > key) lo = mid + 1;
-        else return s16(k + 22 + 6 * (size_t)mid);
+        else return rds16(f, k + 22 + 6 * (size_t)mid);
     }
     return 0;
 }
 
-static const uint8_t *glyph_data(const ntt_font *f, int glyph) {
-    if (glyph < 0 || glyph >= f->num_glyphs) return NULL;
+/* file offset of the glyph's data and one past its end; 0 for an empty glyph (space) or a bad index */
+static size_t glyph_data(const ntt_font *f, int glyph, size_t *end) {
+    if (glyph < 0 || glyph >= f->num_glyphs) return 0;
     uint32_t g0, g1;
     if (f->loc_format == 0) {
-        g0 = 2u * u16(f->data + f->loca + 2 * (size_t)glyph);
-        g1 = 2u * u16(f->data + f->loca + 2 * (size_t)glyph + 2);
+        g0 = 2u * rd16(f, (size_t)f->loca + 2 * (size_t)glyph);
+        g1 = 2u * rd16(f, (size_t)f->loca + 2 * (size_t)glyph + 2);
     } else {
-        g0 = u32(f->data + f->loca + 4 * (size_t)glyph);
-        g1 = u32(f->data + f->loca + 4 * (size_t)glyph + 4);
+        g0 = rd32(f, (size_t)f->loca + 4 * (size_t)glyph);
+        g1 = rd32(f, (size_t)f->loca + 4 * (size_t)glyph + 4);
     }
-    if (g0 == g1 || (size_t)f->glyf + g1 > f->size) return NULL; /* empty glyph (space) */
-    return f->data + f->glyf + g0;
+    if (g1 <= g0 || g1 - g0 < 10 || (size_t)f->glyf + g1 > f->size) return 0;
+    if (end) *end = (size_t)f->glyf + g1;
+    return (size_t)f->glyf + g0;
 }
 
 int ntt_font_glyph_box(const ntt_font *f, int glyph, int *x0, int *y0, int *x1, int *y1) {
-    const uint8_t *g = glyph_data(f, glyph);
+    const size_t g = glyph_data(f, glyph, NULL);
     if (!g) return 0;
-    *x0 = s16(g + 2);
-    *y0 = s16(g + 4);
-    *x1 = s16(g + 6);
-    *y1 = s16(g + 8);
+    *x0 = rds16(f, g + 2);
+    *y0 = rds16(f, g + 4);
+    *x1 = rds16(f, g + 6);
+    *y1 = rds16(f, g + 8);
     return 1;
 }
 
@@ -243,18 +264,21 @@ static void raster_line(raster *r, float x0, float y0, float x1, float y1) {
         x0 = x1; y0 = y1; x1 = tx; y1 = ty;
         dir = -1.0f;
     }
+    if (!(y1 > 0.0f) || !(y0 < (float)r->h)) return; /* above or below the bitmap (or not a number) */
     const float dxdy = (x1 - x0) / (y1 - y0);
     float x = x0;
     if (y0 < 0.0f) x -= y0 * dxdy;
-    int y_begin = (int)floorf(y0), y_end = (int)ceilf(y1);
-    if (y_begin < 0) y_begin = 0;
-    if (y_end > r->h) y_end = r->h;
+    const int y_begin = y0 < 0.0f ? 0 : (int)floorf(y0);
+    const int y_end = y1 > (float)r->h ? r->h : (int)ceilf(y1);
     for (int y = y_begin; y < y_end; y++) {
         float *row = r->acc + (size_t)y * (size_t)(r->w + 2);
         const float top = y0 > (float)y ? y0 : (float)y, bot = y1 < (float)(y + 1) ? y1 : (float)(y + 1);
         const float dy = bot - top, xnext = x + dxdy * dy, d = dy * dir;
         float xa = x < xnext ? x : xnext, xb = x < xnext ? xnext : x;
+        /* outlines of a damaged file may leave the glyph's declared box: left of it a segment still covers every
+         * pixel of its rows, right of it none (column w and w + 1 are scratch) */
         if (xa < 0.0f) xa = 0.0f;
+        if (xa > (float)r->w) xa = (float)r->w;
         if (xb > (float)r->w) xb = (float)r->w;
         if (xb < xa) xb = xa;
         const float xa_floor = floorf(xa), xb_ceil = ceilf(xb);
@@ -308,20 +332,26 @@ uint8_t *ntt_font_glyph_bitmap(const ntt_font *f, int glyph, float scale, int *w
     *height = iy1 - iy0;
     *xoff = ix0;
     *yoff = iy0;
-    const uint8_t *g = glyph_data(f, glyph);
-    if (!g || *width <= 0 || *height <= 0) {
+    size_t g_end = 0;
+    const size_t g = glyph_data(f, glyph, &g_end);
+    /* a bitmap of more than 16 Mpixel is not a tick label (damaged box or an absurd size) */
+    if (!g || *width <= 0 || *height <= 0 || (int64_t)*width * (int64_t)*height > (int64_t)(1 << 24)) {
         *width = *height = 0;
         return NULL;
     }
-    const int n_contours = s16(g);
+    const int n_contours = rds16(f, g);
     if (n_contours <= 0) { /* composite glyph: not needed for the labels */
         *width = *height = 0;
         return NULL;
     }
-    const uint8_t *end_pts = g + 10;
-    const int n_points = u16(end_pts + 2 * (size_t)(n_contours - 1)) + 1;
-    const int n_instr = u16(end_pts + 2 * (size_t)n_contours);
-    const uint8_t *p = end_pts + 2 * (size_t)n_contours + 2 + n_instr;
+    const size_t end_pts = g + 10;
+    const int n_points = (int)rd16(f, end_pts + 2 * (size_t)(n_contours - 1)) + 1;
+    const size_t n_instr = rd16(f, end_pts + 2 * (size_t)n_contours);
+    size_t p = end_pts + 2 * (size_t)n_contours + 2 + n_instr;
+    if (p > g_end) { /* the header runs past the glyph's own data */
+        *width = *height = 0;
+        return NULL;
+    }
     uint8_t *flags = (uint8_t *)malloc((size_t)n_points);
     float *px = (float *)malloc(sizeof(float) * (size_t)n_points), *py = (float *)malloc(sizeof(float) * (size_t)n_points);
     raster r;
@@ -335,20 +365,20 @@ uint8_t *ntt_font_glyph_bitmap(const ntt_font *f, int glyph, float scale, int *w
         return NULL;
     }
     for (int i = 0; i < n_points;) { /* flags, run-length coded */
-        const uint8_t fl = *p++;
+        const uint8_t fl = (uint8_t)rd8(f, p++);
         flags[i++] = fl;
         if (fl & 8) {
-            int rep = *p++;
+            int rep = (int)rd8(f, p++);
             while (rep-- > 0 && i < n_points) flags[i++] = fl;
         }
     }
-    int v = 0;
+    long long v = 0; /* 65536 points of +-32767 do not fit an int */
     for (int i = 0; i < n_points; i++) { /* x deltas */
         if (flags[i] & 2) {
-            const int dx = *p++;
+            const int dx = (int)rd8(f, p++);
             v += (flags[i] & 16) ? dx : -dx;
         } else if (!(flags[i] & 16)) {
-            v += s16(p);
+            v += rds16(f, p);
             p += 2;
         }
         px[i] = (float)v * scale - (float)ix0;
@@ -356,10 +386,10 @@ uint8_t *ntt_font_glyph_bitmap(const ntt_font *f, int glyph, float scale, int *w
     v = 0;
     for (int i = 0; i < n_points; i++) { /* y deltas; bitmap y grows downwards */
         if (flags[i] & 4) {
-            const int dy = *p++;
+            const int dy = (int)rd8(f, p++);
             v += (flags[i] & 32) ? dy : -dy;
         } else if (!(flags[i] & 32)) {
-            v += s16(p);
+            v += rds16(f, p);
             p += 2;
         }
         py[i] = (float)-v * scale - (float)iy0;
@@ -375,8 +405,8 @@ uint8_t *ntt_font_glyph_bitmap(const ntt_font *f, int glyph, float scale, int *w
     }
     int first = 0;
     for (int c = 0; c < n_contours; c++) {
-        const int last = u16(end_pts + 2 * (size_t)c), n = last - first + 1;
-        if (n >= 2 && last < n_points) {
+        const int last = (int)rd16(f, end_pts + 2 * (size_t)c), n = last - first + 1;
+        if (n >= 2 && first >= 0 && last < n_points) {
             int m = 0, s = -1;
             for (int i = 0; i < n; i++) {
                 const int a = first + i, b = first + (i + 1) % n;
@@ -406,7 +436,7 @@ uint8_t *ntt_font_glyph_bitmap(const ntt_font *f, int glyph, float scale, int *w
                 }
             }
         }
-        first = last + 1;
+        if (last + 1 > first) first = last + 1; /* end points must ascend; a contour that does not is skipped */
     }
     free(ex); free(ey); free(eon);
     for (int y = 0; y < r.h; y++) {
