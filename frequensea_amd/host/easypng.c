@@ -117,6 +117,9 @@ uint8_t *read_gray_png(const char *fname, int *width, int *height) {
             int ct = data[9];
             channels = ct == 0 ? 1 : ct == 4 ? 2 : ct == 2 ? 3 : ct == 6 ? 4 : 0;
             if (data[8] != 8 || channels == 0 || data[12] != 0 || w == 0 || h == 0) ok = 0;
+            /* sizes the sweep never produces (and whose byte counts would not fit the arithmetic below) are refused:
+             * the widest stitched image is 2 097 152 x 256, the tallest tile 1024 x 16384 */
+            if (w > (1u << 24) || h > (1u << 24) || (uint64_t)w * (uint64_t)h > ((uint64_t)1 << 33)) ok = 0;
         } else if (memcmp(type, "IDAT", 4) == 0) {
             memcpy(idat + idat_len, data, len);
             idat_len += len;

@@ -36,7 +36,7 @@ struct ntt_font {
 };
 
 /* Every read of the file image goes through these: an offset past the end reads as zero, so a damaged or
- * truncated file can make a label wrong but never makes the reader leave its buffer (tests/fuzz, scripts/fuzz_ntt_font.sh). */
+ * truncated file can make a label wrong but never makes the reader leave its buffer (tests/fuzz, scripts/fuzz_host_readers.sh). */
 static uint32_t rd8(const ntt_font *f, size_t off) { return off < f->size ? f->data[off] : 0u; }
 static uint32_t rd16(const ntt_font *f, size_t off) {
     return (off + 2 <= f->size && off + 2 > off) ? (uint32_t)((f->data[off] << 8) | f->data[off + 1]) : 0u;

@@ -1,4 +1,4 @@
-/* Fuzz driver for frequensea_amd/host/ntt_font.c (test infrastructure; built by scripts/fuzz_ntt_font.sh under
+/* Fuzz driver for frequensea_amd/host/ntt_font.c (test infrastructure; built by scripts/fuzz_host_readers.sh under
  * AddressSanitizer + UndefinedBehaviorSanitizer): truncations and byte flips of a real font file, every surviving
  * load is measured and drawn at two sizes.
  * usage: ntt_font_fuzz FONT.ttf SEED CASES SCRATCH_FILE */

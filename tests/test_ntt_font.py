@@ -231,7 +231,7 @@ def test_rulers_with_truetype_labels(tmp_path):
 def test_damaged_font_files_are_refused_or_render_without_faults(tmp_path):
     """Truncated and bit-flipped copies of a font: ntt_font_load either refuses them or every call on the result
     stays inside the file image (scripts/asan_cpu_tests.sh runs this under AddressSanitizer; the long form --
-    tens of thousands of cases, also aimed at single tables -- is scripts/fuzz_ntt_font.sh, which found the
+    tens of thousands of cases, also aimed at single tables -- is scripts/fuzz_host_readers.sh, which found the
     out-of-box outline and the unchecked table reads this reader now guards against)."""
     L = _lib()
     data = bytearray(open(DEJAVU, "rb").read())
