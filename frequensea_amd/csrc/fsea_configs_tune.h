@@ -48,6 +48,8 @@
 #define FSEA_CFG_8192_B2 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 37022
 #define FSEA_CFG_8192_D2 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 37022
 // 32 x 32 x 8: four adjacent bins per lane in the last pass (16-byte row stores), 2-byte pass-0 loads; with and without nt loads
+// static unit interleave (unit = blockIdx + k * grid) instead of the ticket pools
+#define FSEA_CFG_8192_STATIC 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 39070
 #define FSEA_CFG_8192_W 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, 37022
 #define FSEA_CFG_8192_W2 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, 4254
 // other pass orders / twiddle sources

@@ -901,7 +901,7 @@ struct FftKernel {
     // Sizes whose frames live inside one wavefront have no barrier to publish a ticket with and
     // thousands of independent waves to average over: they keep a static interleave
     // (unit = blockIdx + k * gridDim); the ticket scheme is for the multi-wave sizes.
-    static constexpr bool DYNAMIC = !ONE_WAVE;
+    static constexpr bool DYNAMIC = !ONE_WAVE && (Cfg::OPT & 2048) == 0;  // OPT 2048 (tuning): static interleave at every size
     static constexpr unsigned POOLS = 8;
     static constexpr unsigned NO_UNIT = 0xffffffffu;
 

@@ -150,6 +150,7 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
         EMU_VARIANT(8192, "B2", FSEA_CFG_8192_B2)
         EMU_VARIANT(8192, "D2", FSEA_CFG_8192_D2)
         EMU_VARIANT(8192, "W", FSEA_CFG_8192_W)
+        EMU_VARIANT(8192, "static", FSEA_CFG_8192_STATIC)
         EMU_VARIANT(4096, "nr", FSEA_CFG_4096_LR)
         EMU_VARIANT(2048, "nr", FSEA_CFG_2048_LR)
         EMU_VARIANT(8192, "r1", FSEA_CFG_8192_R1)
