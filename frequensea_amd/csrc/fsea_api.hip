@@ -37,6 +37,7 @@ extern "C" int fsea_kernels_tune_px(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_big(fsea::KernelEntry *out, int cap);
 #endif
 
+#define FSEA_STATIC_UNITS_PER_WG 16u  // measured crossover: profiles/r02_static_vs_ticket_distribution.txt
 #define FSEA_CTR_SLOTS 64u          // ticket-counter slots = streams one plan may be launched on concurrently
 #define FSEA_CTR_WORDS (9u * 32u)  // 8 ticket pools + the finished-workgroups word, one 128-byte line each
 
@@ -247,6 +248,8 @@ struct fsea_plan {
     unsigned n_slots = 0;
     unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics (tuning library)
     int occ[fsea::K_COUNT] = {0, 0, 0, 0, 0, 0};
+    // launches with at most this many units per workgroup use the static interleave, longer ones the ticket pools
+    unsigned static_units_per_wg = FSEA_STATIC_UNITS_PER_WG;
     // staging for the host-buffer entry points
     std::mutex mu;
     void *d_in = nullptr;
@@ -355,6 +358,12 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     a.tw_small = p->d_tw;
     a.tw_def = p->d_tw + p->tw_def_off;
+    // units per workgroup of this launch: few -> static interleave, many -> ticket pools (FftArgs::dynamic_units)
+    {
+        const unsigned grid = grid_for(p, e, p->occ[kind], n_frames);
+        const size_t n_units = (n_frames + (size_t)e->fpw - 1) / (size_t)e->fpw;
+        a.dynamic_units = (n_units > (size_t)p->static_units_per_wg * grid) ? 1u : 0u;
+    }
     if (tiles) {
         a.tile_rows = tiles->rows;
         a.pitch_row = tiles->pitch_row;
@@ -417,6 +426,9 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     p->n = fft_size;
     p->hop = hop;
     p->mode = mode;
+#ifdef FSEA_TUNE  // measurement only: FSEA_STATIC_UNITS=0 forces the ticket pools, a large value the static interleave
+    if (const char *su = std::getenv("FSEA_STATIC_UNITS")) p->static_units_per_wg = (unsigned)std::strtoul(su, nullptr, 10);
+#endif
     p->device = device;
     p->entry = e;
     p->num_cu = prop.multiProcessorCount;

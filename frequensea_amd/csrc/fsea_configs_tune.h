@@ -48,6 +48,11 @@
 #define FSEA_CFG_8192_B2 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 37022
 #define FSEA_CFG_8192_D2 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 37022
 // 32 x 32 x 8: four adjacent bins per lane in the last pass (16-byte row stores), 2-byte pass-0 loads; with and without nt loads
+// issue priority between the two workgroups of a CU: alternating per frame (65536), catching up with the pool's average (131072)
+#define FSEA_CFG_8192_PALT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 102558
+#define FSEA_CFG_8192_PCATCH 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 168094
+#define FSEA_CFG_4096_STATIC 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 39102
+#define FSEA_CFG_16384_STATIC 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 39048
 // static unit interleave (unit = blockIdx + k * grid) instead of the ticket pools
 #define FSEA_CFG_8192_STATIC 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 39070
 #define FSEA_CFG_8192_W 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, 37022

@@ -322,6 +322,8 @@ struct FftArgs {
     // (V1 schedule only; tile_rows is a multiple of FPW, so a unit never straddles tiles.)
     uint32_t tile_rows = 0, pitch_row = 0, pitch_tile = 0;
     size_t out_span = 0;
+    // multi-wave sizes: 1 = units handed out by the ticket pools, 0 = static interleave (unit = blockIdx + k * grid)
+    uint32_t dynamic_units = 1;
 };
 
 // ---------------------------------------------------------------------------
@@ -1244,9 +1246,13 @@ struct FftKernel {
         // the latencies overlap: the ticket for the second unit, unit 0's bytes (HBM
         // starts streaming at once), the register-resident last-pass twiddles, then the
         // middle-pass tables for LDS.
-        size_t u = b;  // static interleave (single-wave frames)
+        size_t u = b;  // static interleave (single-wave frames; short launches of the multi-wave sizes)
         unsigned tick_next = 0;
-        if constexpr (DYNAMIC) {
+        // The ticket pools pay for themselves when a workgroup gets many units (they even out the unequal progress of
+        // workgroups and XCDs); with a handful each, the plain interleave is faster -- no atomics, no ticket word to wait
+        // for, nothing to steal at the end (profiles/r02_static_vs_ticket_distribution.txt).  The host decides per launch.
+        const bool dyn = DYNAMIC && a.dynamic_units != 0;
+        if (dyn) {
             u = (size_t)pools.start(cur) + b / POOLS;         // static first unit
             if (u >= pools.start(cur + 1)) u = n_units;       // more workgroups than units in this pool
         }
@@ -1270,7 +1276,7 @@ struct FftKernel {
         }
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
-        if constexpr (DYNAMIC) {
+        if (dyn) {
             if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
         }
 
@@ -1318,7 +1324,7 @@ struct FftKernel {
         // A workgroup whose static unit does not exist still has to look for work (another
         // pool may be long): resolve its first ticket synchronously.
         unsigned par = 0;
-        if (DYNAMIC && u >= n_units) {
+        if (dyn && u >= n_units) {
             if (issuer) {
                 unsigned nu = pools.unit(cur, tick_next);
                 for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
@@ -1343,7 +1349,7 @@ struct FftKernel {
             // pool it came from is exhausted, steal from the others (synchronous; this only
             // happens at the end of a launch).  Published to the workgroup by the first
             // barrier of this iteration.
-            if (DYNAMIC && issuer) {
+            if (dyn && issuer) {
                 unsigned nu = pools.unit(cur, tick_next);
                 for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
                     const unsigned q = (cur + k) % POOLS;
@@ -1394,18 +1400,36 @@ struct FftKernel {
                 const unsigned tkv = tk[par];
                 middle_pass<1>(lds, lds_all, v, a, t, tw1, [&]() {
                     __builtin_amdgcn_sched_barrier(0);
-                    const unsigned nu = __builtin_amdgcn_readfirstlane(tkv);
-                    par ^= 1u;
-                    un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+                    if (dyn) {
+                        const unsigned nu = __builtin_amdgcn_readfirstlane(tkv);
+                        par ^= 1u;
+                        un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+                    }
                     load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff,
                              raw);
                 });
             } else {
-                if constexpr (DYNAMIC) {
+                if (dyn) {
                     if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
                     const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
                     par ^= 1u;
                     un = (nu == NO_UNIT) ? n_units : (size_t)nu;
+                    // OPT 65536 (tuning): the two workgroups of a CU take turns at the higher issue priority, frame by frame;
+                    // OPT 131072 (tuning): a workgroup that has had fewer units than its pool's average so far raises its
+                    // priority, one that is ahead lowers it (the unit number says how many the pool has handed out)
+                    if constexpr ((Cfg::OPT & 65536) != 0) {
+                        if ((iter + (blockIdx.x >= gridDim.x / 2 ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(2);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                    if constexpr ((Cfg::OPT & 131072) != 0) {
+                        if (nu != NO_UNIT) {
+                            const unsigned q = (unsigned)(((size_t)nu * POOLS) / pools.n_units);  // pool the unit came from
+                            const unsigned handed = nu - pools.start(q < POOLS ? q : POOLS - 1);
+                            const unsigned mine = (iter + 2u) * pools.homed(b % POOLS);         // units this workgroup has had, scaled
+                            if (mine < handed) __builtin_amdgcn_s_setprio(3);
+                            else __builtin_amdgcn_s_setprio(0);
+                        }
+                    }
                 }
                 if constexpr ((Cfg::ABL & 64) == 0) {  // ABL 64 (measurement only): the first unit's bytes are reused
                     load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
@@ -1448,7 +1472,7 @@ struct FftKernel {
 
         // this worker is done: its outstanding ticket request must have landed before it is
         // counted, so that the last worker's reset cannot be overtaken by a late increment
-        if (DYNAMIC && issuer) {
+        if (dyn && issuer) {
             __builtin_amdgcn_s_waitcnt(0);
             const unsigned finished = atomicAdd(a.ctr + 32 * POOLS, 1u);
             if (finished == gridDim.x - 1) {

@@ -15,7 +15,7 @@ fsea.use_tune_library()
 
 VARIANTS = {
     8192: ["", "cp0", "r1", "nd", "st_nt", "st_sc1", "st_sc0sc1", "st_sc1nt", "ld_nt", "x0", "x7", "tk", "pr", "v2", "v2s",
-           "A", "B", "D", "B2", "D2", "W", "W2", "static", "notwl", "notwr",
+           "A", "B", "D", "B2", "D2", "W", "W2", "static", "palt", "pcatch", "notwl", "notwr",
            "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu", "abl_noload", "abl_nomag",
            "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na",
            "abl_io_nt_ws", "abl_io_nt_wl", "abl_io_nt_wls", "abl_ws", "abl_wl", "abl_wls", "abl_px_nolog", "abl_px_wide"],

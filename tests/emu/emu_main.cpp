@@ -113,6 +113,10 @@ extern "C" void emu_set_shift(double cycles_per_sample, double phase0_cycles) {
     g_rot_phase0 = phase0_cycles;
 }
 
+// unit distribution of the multi-wave sizes (FftArgs::dynamic_units): sticky until set again
+static uint32_t g_dynamic_units = 1;
+extern "C" void emu_set_dynamic_units(uint32_t on) { g_dynamic_units = on; }
+
 // tiled output (FftArgs::tile_rows ...): set before a call, cleared by it
 static uint32_t g_tile_rows = 0, g_pitch_row = 0, g_pitch_tile = 0;
 static size_t g_out_span = 0;
@@ -132,6 +136,7 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.pitch_row = g_pitch_row;
     a.pitch_tile = g_pitch_tile;
     a.out_span = g_out_span;
+    a.dynamic_units = g_dynamic_units;
     g_tile_rows = 0;
     a.in = in;
     a.out = out;

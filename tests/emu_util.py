@@ -46,9 +46,12 @@ def emu_lib():
 
 
 def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0, variant="",
-             shift=None):
-    """shift = (cycles_per_sample, phase0_cycles) selects the frequency-shifted u8 kernel (in_kind 2)."""
+             shift=None, dynamic_units=True):
+    """shift = (cycles_per_sample, phase0_cycles) selects the frequency-shifted u8 kernel (in_kind 2);
+    dynamic_units=False runs the multi-wave sizes with the static unit interleave (FftArgs::dynamic_units = 0)."""
     hop = n if hop is None else hop
+    emu_lib().emu_set_dynamic_units.argtypes = [ctypes.c_uint32]
+    emu_lib().emu_set_dynamic_units(1 if dynamic_units else 0)
     if shift is not None:
         in_kind = 2
         emu_lib().emu_set_shift.argtypes = [ctypes.c_double, ctypes.c_double]

@@ -182,3 +182,13 @@ def test_tiled_output_addressing(n, tile_rows, mode):
     for k in range(tiles):
         want[:tile_rows, first_x + k * step: first_x + k * step + n] = rows[k * tile_rows:(k + 1) * tile_rows]
     assert np.array_equal(image, want)
+
+
+@pytest.mark.parametrize("n,nf,grid", [(8192, 7, 3), (8192, 2, 4), (4096, 9, 2), (4096, 3, 3), (16384, 5, 2)])
+def test_static_unit_interleave_of_the_multi_wave_sizes(n, nf, grid):
+    """Short launches of the 4096 / 8192 / 16384-point kernels run without the ticket pools (FftArgs::dynamic_units = 0):
+    ragged unit counts, more workgroups than units, odd frame counts at two frames per workgroup."""
+    iq = synth_iq(n + nf, 2 * nf * n)
+    for mode in (0, 2):
+        got = emu_rows(iq, n, nf, mode=mode, grid=grid, dynamic_units=False)
+        parity.check_mode(got, iq, n, nf, n, True, mode)
