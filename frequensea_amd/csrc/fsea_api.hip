@@ -39,7 +39,7 @@ extern "C" int fsea_kernels_tune_big(fsea::KernelEntry *out, int cap);
 
 #define FSEA_STATIC_UNITS_PER_WG 16u  // measured crossover: profiles/r02_static_vs_ticket_distribution.txt
 #define FSEA_CTR_SLOTS 64u          // ticket-counter slots = streams one plan may be launched on concurrently
-#define FSEA_CTR_WORDS (9u * 32u)  // 8 ticket pools + the finished-workgroups word, one 128-byte line each
+#define FSEA_CTR_WORDS (9u * 32u + 2048u)  // 8 ticket pools + the finished-workgroups word, one 128-byte line each; one progress word per workgroup (tuning option)
 
 namespace {
 

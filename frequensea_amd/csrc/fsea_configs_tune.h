@@ -50,6 +50,10 @@
 // 32 x 32 x 8: four adjacent bins per lane in the last pass (16-byte row stores), 2-byte pass-0 loads; with and without nt loads
 // issue priority between the two workgroups of a CU: alternating per frame (65536), catching up with the pool's average (131072)
 #define FSEA_CFG_8192_PALT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 102558
+// the younger workgroup of every CU (block >= grid / 2) at a constant higher priority (the older one wins the arbitration
+// otherwise: 39 vs 53 us for the same 8 frames), levels 1, 2, 3
+#define FSEA_CFG_8192_PY1 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 38046
+#define FSEA_CFG_8192_PPAIR 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 299166
 #define FSEA_CFG_8192_PCATCH 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 168094
 #define FSEA_CFG_4096_STATIC 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 39102
 #define FSEA_CFG_16384_STATIC 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 39048

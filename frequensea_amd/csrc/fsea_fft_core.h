@@ -1360,6 +1360,17 @@ struct FftKernel {
                 tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
             }
 
+            // OPT 262144 (tuning): the two workgroups of a CU (blocks b and b + grid / 2) tell each other how many frames they
+            // have done; the one behind raises its issue priority, the one ahead lowers it
+            [[maybe_unused]] unsigned partner_progress = 0;
+            if constexpr ((Cfg::OPT & 262144) != 0) {
+                unsigned *prog = a.ctr + 9 * 32;
+                const unsigned half = gridDim.x >> 1;
+                const unsigned partner = b < half ? b + half : b - half;
+                if (tid == 0) __hip_atomic_store(prog + b, iter + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                partner_progress = __hip_atomic_load(prog + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+
             // A lane without a frame (ragged last unit) still runs the barriers; it simply
             // transforms the zeros its loads returned and its stores are dropped.
             cf v[P];
@@ -1409,6 +1420,16 @@ struct FftKernel {
                              raw);
                 });
             } else {
+                if constexpr ((Cfg::OPT & 65536) != 0) {
+                    if ((iter + (blockIdx.x >= gridDim.x / 2 ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                if constexpr ((Cfg::OPT & 262144) != 0) {
+                    const unsigned pp = __builtin_amdgcn_readfirstlane(partner_progress);
+                    if (pp > iter + 1u) __builtin_amdgcn_s_setprio(3);
+                    else if (pp < iter + 1u) __builtin_amdgcn_s_setprio(0);
+                    else __builtin_amdgcn_s_setprio(1);
+                }
                 if (dyn) {
                     if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
                     const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
@@ -1417,10 +1438,6 @@ struct FftKernel {
                     // OPT 65536 (tuning): the two workgroups of a CU take turns at the higher issue priority, frame by frame;
                     // OPT 131072 (tuning): a workgroup that has had fewer units than its pool's average so far raises its
                     // priority, one that is ahead lowers it (the unit number says how many the pool has handed out)
-                    if constexpr ((Cfg::OPT & 65536) != 0) {
-                        if ((iter + (blockIdx.x >= gridDim.x / 2 ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(2);
-                        else __builtin_amdgcn_s_setprio(0);
-                    }
                     if constexpr ((Cfg::OPT & 131072) != 0) {
                         if (nu != NO_UNIT) {
                             const unsigned q = (unsigned)(((size_t)nu * POOLS) / pools.n_units);  // pool the unit came from
@@ -1470,6 +1487,9 @@ struct FftKernel {
             ++iter;
         }
 
+        if constexpr ((Cfg::OPT & 262144) != 0) {
+            if (tid == 0) __hip_atomic_store(a.ctr + 9 * 32 + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch
+        }
         // this worker is done: its outstanding ticket request must have landed before it is
         // counted, so that the last worker's reset cannot be overtaken by a late increment
         if (dyn && issuer) {

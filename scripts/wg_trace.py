@@ -62,3 +62,20 @@ pro = (tr[:, 6].astype(np.int64) - tr[:, 0].astype(np.int64)) / 100.0
 p0 = (tr[:, 7].astype(np.int64) - tr[:, 0].astype(np.int64)) / 100.0
 print("prologue done after %.2f us (mean), first pass 0 + barrier after %.2f us, first iteration ends after %.2f us"
       % (pro.mean(), p0.mean(), np.nanmean(its[:, 0])))
+# which workgroups share a CU, and how their durations and frame counts relate
+pairs = collections.defaultdict(list)
+for blk in range(grid):
+    pairs[(int(xcc[blk]), int(se[blk]), int(sh[blk]), int(cu[blk]))].append(blk)
+diffs = collections.Counter(tuple(sorted(v))[1] - tuple(sorted(v))[0] for v in pairs.values() if len(v) == 2)
+print("block-index distance of the two workgroups of a CU: " + str(sorted(diffs.items(), key=lambda kv: -kv[1])[:6]))
+n_iter = valid.sum(axis=1)
+two = [sorted(v) for v in pairs.values() if len(v) == 2]
+if two:
+    lo = np.array([min(dur[a], dur[b]) for a, b in two])
+    hi = np.array([max(dur[a], dur[b]) for a, b in two])
+    first_faster = np.mean([dur[a] < dur[b] for a, b in two])
+    cu_end = np.array([max(en[a], en[b]) for a, b in two])
+    print("per CU: faster workgroup %.2f us, slower %.2f us (means); the lower block index is the faster one in %.0f %% of the CUs"
+          % (lo.mean(), hi.mean(), 100 * first_faster))
+    print("per CU end (last of its two workgroups): min %.2f  p50 %.2f  max %.2f us; iterations per workgroup: min %d max %d"
+          % (cu_end.min(), np.median(cu_end), cu_end.max(), n_iter.min(), n_iter.max()))

@@ -50,7 +50,7 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
         twd_p = twd.data() + 1;
     }
     a.tw_def = reinterpret_cast<const fsea::cf *>(twd_p);
-    std::vector<unsigned> ctr(9 * 32, 0u);
+    std::vector<unsigned> ctr(9 * 32 + 2048, 0u);
     a.ctr = ctr.data();
     for (unsigned b = 0; b < grid; ++b) {
         std::vector<fsea::cf> lds_store(Cfg::LDS_ALLOC + 2);

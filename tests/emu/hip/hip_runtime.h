@@ -33,6 +33,9 @@ unsigned emu_readfirstlane(unsigned v);
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 #define __builtin_amdgcn_s_waitcnt(n) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 // clang vector builtins used by the packed-math code, for g++ vector_size types
