@@ -497,6 +497,8 @@ def main():
     # initialises, so it has to be set before torch touches the device; libfsea_hip.so sets the same
     # default for hosts that load it first.
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    # multi-process GPU work on these hosts needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with the legacy mode)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
