@@ -248,8 +248,9 @@ struct fsea_plan {
     unsigned n_slots = 0;
     unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics (tuning library)
     int occ[fsea::K_COUNT] = {0, 0, 0, 0, 0, 0};
-    // launches with at most this many units per workgroup use the static interleave, longer ones the ticket pools
-    unsigned static_units_per_wg = FSEA_STATIC_UNITS_PER_WG;
+    // FSEA_UNITS_AUTO: launches with at most FSEA_STATIC_UNITS_PER_WG units per workgroup use the static interleave,
+    // longer ones the ticket pools; fsea_plan_set_unit_distribution pins one of the two
+    int units_policy = FSEA_UNITS_AUTO;
     // staging for the host-buffer entry points
     std::mutex mu;
     void *d_in = nullptr;
@@ -362,7 +363,9 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     {
         const unsigned grid = grid_for(p, e, p->occ[kind], n_frames);
         const size_t n_units = (n_frames + (size_t)e->fpw - 1) / (size_t)e->fpw;
-        a.dynamic_units = (n_units > (size_t)p->static_units_per_wg * grid) ? 1u : 0u;
+        a.dynamic_units = p->units_policy == FSEA_UNITS_TICKETS  ? 1u
+                          : p->units_policy == FSEA_UNITS_STATIC ? 0u
+                                                                 : (n_units > (size_t)FSEA_STATIC_UNITS_PER_WG * grid ? 1u : 0u);
     }
     if (tiles) {
         a.tile_rows = tiles->rows;
@@ -426,9 +429,6 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     p->n = fft_size;
     p->hop = hop;
     p->mode = mode;
-#ifdef FSEA_TUNE  // measurement only: FSEA_STATIC_UNITS=0 forces the ticket pools, a large value the static interleave
-    if (const char *su = std::getenv("FSEA_STATIC_UNITS")) p->static_units_per_wg = (unsigned)std::strtoul(su, nullptr, 10);
-#endif
     p->device = device;
     p->entry = e;
     p->num_cu = prop.multiProcessorCount;
@@ -520,6 +520,15 @@ int fsea_plan_destroy(fsea_plan *p) {
 size_t fsea_plan_row_bytes(const fsea_plan *p) { return p ? (size_t)p->n * mode_elem_bytes(p->mode) : 0; }
 int fsea_plan_fft_size(const fsea_plan *p) { return p ? p->n : 0; }
 const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_name.c_str() : ""; }
+
+int fsea_plan_set_unit_distribution(fsea_plan *p, int policy) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    if (policy != FSEA_UNITS_AUTO && policy != FSEA_UNITS_STATIC && policy != FSEA_UNITS_TICKETS) {
+        return fail(FSEA_EINVAL, "unknown unit distribution %d", policy);
+    }
+    p->units_policy = policy;
+    return FSEA_OK;
+}
 
 int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned *block, size_t *lds_bytes) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");

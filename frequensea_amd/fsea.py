@@ -7,6 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
+UNITS_AUTO, UNITS_STATIC, UNITS_TICKETS = 0, 1, 2
 MODE_MAG_F32 = 0
 MODE_DB10_U8 = 1
 MODE_DB5_U8_DCFIX = 2
@@ -22,7 +23,7 @@ _MODE_DTYPE = {
 # Every symbol include/fsea.h declares; tests check the built library exports all of them.
 EXPORTS = [
     "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_reset",
-    "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device", "fsea_exec_u8_tiled_device",
+    "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device", "fsea_exec_u8_tiled_device", "fsea_plan_set_unit_distribution",
     "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_exec_u8_shifted_device", "fsea_exec_u8_shifted_host", "fsea_mean_magnitude_u8_device",
     "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
     "fsea_copy_to_host", "fsea_stream_synchronize",
@@ -106,6 +107,7 @@ def hip_lib():
         L.fsea_plan_kernel_name.restype = ctypes.c_char_p
         L.fsea_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp]
         L.fsea_exec_u8_tiled_device.argtypes = [vp, vp, sz, ci, vp, sz, sz, sz, sz, sz, vp]
+        L.fsea_plan_set_unit_distribution.argtypes = [vp, ci]
         L.fsea_exec_u8_host.argtypes = [vp, vp, sz, ci, vp]
         L.fsea_exec_f64_host.argtypes = [vp, vp, sz, vp]
         L.fsea_exec_u8_shifted_device.argtypes = [vp, vp, sz, ci, ctypes.c_double, ctypes.c_double, vp, vp]
@@ -193,6 +195,10 @@ class Plan:
         tile f // tile_rows, tile k at columns first_x + k * tile_step."""
         _check(self._L.fsea_exec_u8_tiled_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_image_ptr, image_rows,
                                                  image_stride, first_x, tile_rows, tile_step, stream or None))
+
+    def set_unit_distribution(self, policy):
+        """UNITS_AUTO (default), UNITS_STATIC or UNITS_TICKETS: fsea_plan_set_unit_distribution."""
+        _check(self._L.fsea_plan_set_unit_distribution(self._p, policy))
 
     def reset(self):
         _check(self._L.fsea_plan_reset(self._p))

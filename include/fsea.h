@@ -89,6 +89,17 @@ int fsea_plan_grid(const fsea_plan *plan, size_t n_frames, unsigned *grid, unsig
 size_t fsea_plan_row_bytes(const fsea_plan *plan);
 int fsea_plan_fft_size(const fsea_plan *plan);
 
+/* How a launch's frames are handed to the persistent workgroups of the sizes whose frames span several wavefronts
+ * (4096 points and up): FSEA_UNITS_TICKETS = atomic ticket pools per XCD with stealing (evens out unequal progress;
+ * best from about 32 frames per workgroup), FSEA_UNITS_STATIC = unit k of workgroup b is b + k * grid (no atomics;
+ * best for short launches), FSEA_UNITS_AUTO (default) = chosen per launch by its length.  Results are identical; the
+ * setting exists for measurements and tests.  Takes effect from the next launch; not to be changed while another
+ * thread is launching the plan. */
+#define FSEA_UNITS_AUTO 0
+#define FSEA_UNITS_STATIC 1
+#define FSEA_UNITS_TICKETS 2
+int fsea_plan_set_unit_distribution(fsea_plan *plan, int policy);
+
 /* Device-resident execution.  d_iq: device pointer to interleaved 8-bit IQ,
  * at least 2*((n_frames-1)*hop + fft_size) bytes, 16-byte aligned.
  * flip != 0: bytes are raw HackRF int8 and the kernel applies b ^ 0x80

@@ -65,6 +65,8 @@ def main():
         for var in names:
             try:
                 plans.append((var, fsea.Plan(n, variant=var, mode=MODE)))
+                if os.environ.get("TUNE_UNITS"):   # static | tickets: pin the frame distribution (default: per launch)
+                    plans[-1][1].set_unit_distribution({"static": fsea.UNITS_STATIC, "tickets": fsea.UNITS_TICKETS}[os.environ["TUNE_UNITS"]])
             except fsea.FseaError as e:
                 print("N=%d variant=%-6s unavailable: %s" % (n, var, e))
         # warm the clocks, then interleave the variants over several rounds so that order,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Static interleave vs ticket pools by launch length (tuning library): FSEA_STATIC_UNITS forces one or the other for the
-plans created while it is set.  Rotating buffer sets (streaming regime), interleaved rounds.
+"""Static interleave vs ticket pools by launch length: two plans with the distribution pinned either way
+(fsea_plan_set_unit_distribution).  Rotating buffer sets (streaming regime), interleaved rounds.
 Usage: python scripts/units_mode_sweep.py N [N ...]"""
 import ctypes
 import os
@@ -32,9 +32,9 @@ for n in [int(a) for a in sys.argv[1:]] or [8192]:
     for d in d_ins:
         fsea._check(L.fsea_copy_to_device(0, d, host.ctypes.data, host.nbytes))
     plans = {}
-    for name, val in (("tickets", "0"), ("static", "1000000")):
-        os.environ["FSEA_STATIC_UNITS"] = val
+    for name, policy in (("tickets", fsea.UNITS_TICKETS), ("static", fsea.UNITS_STATIC)):
         plans[name] = fsea.Plan(n, mode=MODE)
+        plans[name].set_unit_distribution(policy)
     grid = plans["static"].grid(max_frames)[0]
     frames = 256
     while frames <= max_frames:

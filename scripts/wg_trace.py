@@ -21,6 +21,8 @@ host = np.random.default_rng(1).integers(-70, 70, 2 * n * frames, dtype=np.int8)
 for d in d_in:
     fsea._check(L.fsea_copy_to_device(0, d, host.ctypes.data, host.nbytes))
 plan = fsea.Plan(n, variant=os.environ.get("FSEA_VARIANT"))
+if os.environ.get("FSEA_UNITS"):          # static | tickets: pin the frame distribution (default: per launch)
+    plan.set_unit_distribution({"static": fsea.UNITS_STATIC, "tickets": fsea.UNITS_TICKETS}[os.environ["FSEA_UNITS"]])
 grid = plan.grid(frames)[0]
 for k in range(200):                      # warm clocks, rotate buffers
     plan.exec_device(d_in[k % sets], frames, d_out[k % sets])

@@ -41,6 +41,22 @@ class DeviceBuffer:
             self.ptr = ctypes.c_void_p()
 
 
+@pytest.fixture(params=["auto", "tickets", "static"])
+def units_policy(request, monkeypatch):
+    """Runs a test with the frame distribution of the multi-wave sizes left to the library (per launch length) and
+    pinned either way (fsea_plan_set_unit_distribution): short test launches would otherwise never reach the ticket pools."""
+    policy = {"auto": fsea.UNITS_AUTO, "tickets": fsea.UNITS_TICKETS, "static": fsea.UNITS_STATIC}[request.param]
+    real = fsea.Plan
+
+    def make(*args, **kwargs):
+        plan = real(*args, **kwargs)
+        plan.set_unit_distribution(policy)
+        return plan
+
+    monkeypatch.setattr(fsea, "Plan", make)
+    return request.param
+
+
 def test_device_present_and_library_loaded():
     assert fsea.device_count() >= 1
     p = fsea.Plan(8192)
@@ -94,7 +110,7 @@ def test_overlapped_frames(n, hop):
     plan.close()
 
 
-def test_random_geometry_sweep_on_gpu():
+def test_random_geometry_sweep_on_gpu(units_policy):
     rng = np.random.default_rng(7)
     for _ in range(40):
         n = int(rng.choice(SIZES))
@@ -242,7 +258,7 @@ def test_device_resident_and_ragged_counts():
     plan.close()
 
 
-def test_repeated_launches_reset_their_ticket_counters():
+def test_repeated_launches_reset_their_ticket_counters(units_policy):
     """Frames are handed out by atomic ticket counters that the last workgroup of a launch resets;
     a stale counter would make a later launch skip frames.  Launch the same plan many times with
     changing frame counts (more than the 64 counter slots) and check every row each time."""
@@ -284,7 +300,7 @@ def test_zero_frames_and_single_frame():
     plan.close()
 
 
-def test_concurrent_launches_of_one_plan_on_two_streams():
+def test_concurrent_launches_of_one_plan_on_two_streams(units_policy):
     """Every launch draws its own ticket-counter slot, so launches of one plan may overlap on
     different streams.  Two HIP streams, interleaved launches into separate outputs."""
     hip = ctypes.CDLL("libamdhip64.so")
@@ -315,7 +331,7 @@ def test_concurrent_launches_of_one_plan_on_two_streams():
     plan.close()
 
 
-def test_many_overlapping_launches_on_four_streams_and_reset():
+def test_many_overlapping_launches_on_four_streams_and_reset(units_policy):
     """One ticket-counter slot per stream (launches on a stream run in order; streams never share a
     slot): far more than 64 launches in flight over four streams, multi-wave size, every launch
     checked.  Then fsea_plan_reset, and the plan still works on a fifth stream."""
@@ -763,7 +779,7 @@ def test_linearity_and_bitwise_reproducibility_at_full_size():
 
 @pytest.mark.parametrize("n,nf,mode", [(128, 33, 1), (1024, 9, 0), (2048, 5, 3), (4096, 3, 2), (8192, 13, 0),
                                        (8192, 1, 5), (16384, 2, 1)])
-def test_no_write_outside_the_output_rows(n, nf, mode):
+def test_no_write_outside_the_output_rows(n, nf, mode, units_policy):
     """Ragged launches (frame counts that do not fill the last unit, fewer frames than workgroups)
     must not touch a byte before or after their n_frames rows: guard bands around the output."""
     guard = 1 << 16
