@@ -110,7 +110,11 @@ int fsea_plan_set_unit_distribution(fsea_plan *plan, int policy);
  * is current.  Asynchronous with respect to the host.
  * A plan may be launched from several host threads and on up to 64 different streams; launches on
  * one stream run in order, launches on different streams may overlap.  The calls leave the
- * caller's current HIP device unchanged. */
+ * caller's current HIP device unchanged.
+ * The call enqueues exactly one kernel and nothing else, so it may be stream-captured into a hipGraph
+ * (launch-bound consumers: tests/test_gpu_parity.py::test_launches_can_be_captured_into_a_hip_graph).  A captured
+ * launch keeps the ticket-counter slot of the stream it was captured on: replay one instance of such a graph at a
+ * time. */
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
                         void *d_out, void *stream);
 

@@ -1106,3 +1106,43 @@ def test_lua_scene_draw_loop_replay(golden, tmp_path, scene, history_mode):
         L.nrf_freq_shifter_free(shifter)
     L.nrf_device_free(dev)
     L.nrf_fft_free(fft)
+
+
+def test_launches_can_be_captured_into_a_hip_graph():
+    """fsea_exec_u8_device issues nothing but a kernel launch on the caller's stream, so a sequence of launches can be
+    stream-captured (torch.cuda.graph = hipGraph on ROCm) and replayed: the launch-bound form of a consumer's inner loop.
+    Both frame distributions, two sizes; the replayed rows equal the directly launched ones bit for bit."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    for n, nf, policy in ((8192, 96, fsea.UNITS_AUTO), (8192, 96, fsea.UNITS_TICKETS), (1024, 500, fsea.UNITS_AUTO)):
+        plan = fsea.Plan(n)
+        plan.set_unit_distribution(policy)
+        iqs = [torch.from_numpy(synth_iq(70 + k, 2 * nf * n).copy()).to(dev) for k in range(4)]
+        outs = [torch.zeros(nf * n, dtype=torch.float32, device=dev) for _ in range(4)]
+        want = []
+        for k in range(4):
+            plan.exec_device(iqs[k].data_ptr(), nf, outs[k].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = [o.clone() for o in outs]
+        for o in outs:
+            o.zero_()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm the stream's counter slot outside the capture
+            plan.exec_device(iqs[0].data_ptr(), nf, outs[0].data_ptr(), stream=side.cuda_stream)
+        torch.cuda.synchronize()
+        outs[0].zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for k in range(4):
+                plan.exec_device(iqs[k].data_ptr(), nf, outs[k].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):
+            for o in outs:
+                o.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            for k in range(4):
+                assert torch.equal(outs[k], want[k]), (n, policy, rep, k)
+        parity.check_mode(want[1].cpu().numpy().reshape(nf, n), iqs[1].cpu().numpy(), n, nf, n, True, 0)
+        del graph
+        plan.close()
