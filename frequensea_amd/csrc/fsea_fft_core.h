@@ -259,16 +259,25 @@ struct FftCfg {
     //     puts two lanes of every ds_read_b128 lane group on one slot (8 instead of 4 LDS cycles
     //     per instruction; scripts/lds_conflicts.py); rotated, the groups are conflict-free;
     // 32 = the same renumbering for the last pass (and the cross-block form for 8-byte layouts, see
-    //     pass_lane); measured null, off everywhere.
+    //     pass_lane); on where the last pass has that shape (4096 points), worth nothing in time.
     // 128 = the middle pass's twiddles are deferred into the butterflies (dft_regs_def) and kept in
     //     registers for the workgroup's lifetime: R/2 pairs per column instead of R-1 LDS reads per frame;
     // 256 = the +-i butterflies as packed FMAs by (+-1, -+1) instead of packed adds (the round-1 form);
     // 512 = ticket sizes: the ticket word is waited for behind pass 1's LDS reads, not in front of them;
     // 64 = the V2 schedule (run_v2): first exchange inside each wavefront, two barriers per frame,
     //     middle-pass twiddles deferred into the butterflies and kept in registers.
+    // Cache policy: 4096 = row stores nt (where a store writes a whole 128-byte line per frame, st_aux),
+    //     8192 = sc1, 16384 = sc0 (tuning), 32768 = input loads nt.
+    // Product configurations (fsea_configs.h) use the bits above only.  Tuning-library experiments, all measured
+    // and rejected: 1024 = constant higher priority for the younger workgroup of a CU,
+    //     2048 = static unit interleave compiled in (the product chooses per launch: FftArgs::dynamic_units),
+    //     65536 = the two workgroups of a CU alternate priority per frame, 131072 = priority by the pool's average
+    //     progress, 262144 = priority by the partner workgroup's published progress.
     static constexpr int OPT = OPT_;
     // ABL: measurement-only ablations (tuning variants, results are wrong by design):
-    // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles.
+    // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles, 8 / 16 / 32 = V2-schedule
+    // ablations, 64 = no per-frame loads, 128 = no magnitude arithmetic / no logarithm, 256 = rows stored 16 bytes per
+    // lane (misplaced), 512 = frame loaded 16 bytes per lane (misplaced).  Always 0 in the product configurations.
     static constexpr int ABL = ABL_;
     static constexpr int N = N_, T = T_, FPW = FPW_, NP = NP_;
     static constexpr int WPE = WPE_;  // waves per SIMD the register budget must allow
