@@ -1,0 +1,57 @@
+"""bench.py's contract with the driver: one JSON line with the fields the task statement names (GPU tier), and a
+loud refusal -- not a CPU fallback -- when there is no GPU (CPU tier)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="this machine has a GPU")
+def test_bench_and_smoke_refuse_to_run_without_a_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+    assert "metric" not in r.stdout                                   # no line, no number
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=600)
+    assert r.returncode != 0 and "__SMOKE_OK__" not in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--cpu-budget", "1.0"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "fft_frames_per_sec_n8192" and d["unit"] == "frames/s" and d["n_gpus"] == 1
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.2 < roof["frac"] < 1.0
+    assert roof["kernel"] == "fsea_fft8192_u8_mag"
+    assert roof["traffic"] is None or 0.9 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.2
+    # value = frames of all ranks / wall time of the timed steps; the kernel time cannot exceed the step time
+    assert abs(d["value"] - 4096 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    assert roof["avg_launch_ms"] <= d["ms_per_step"] * 1.02
+    cb = d["cpu_baseline"]
+    assert cb["unit"] == "frames/s" and cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert isinstance(cb["sample"], str) and cb["sample"]
