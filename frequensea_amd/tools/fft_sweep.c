@@ -274,6 +274,10 @@ int main(int argc, char **argv) {
     if (cfg.fft_size < 0) cfg.fft_size = cfg.broad ? 256 : 1024;        /* FFT_SIZE */
     if (cfg.rows_wanted < 0) cfg.rows_wanted = cfg.broad ? 4096 : 16384; /* FFT_HISTORY_SIZE */
     if (step < 0) step = cfg.broad ? 5.0 : 2.0;                          /* FREQUENCY_STEP */
+    if (cfg.rows_wanted < 1 || cfg.skip < 0 || cfg.fft_size < 1) {
+        fprintf(stderr, "ERROR: --rows and --fft must be positive, --skip not negative\n");
+        return EXIT_FAILURE;
+    }
     const uint32_t sample_rate = 5000000;                                /* SAMPLE_RATE */
     if (!(step > 0.0) || (uint64_t)(step * 1e6 + 0.5) > (uint64_t)sample_rate || (uint64_t)(step * 1e6 + 0.5) == 0) {
         fprintf(stderr, "ERROR: --step must be in (0, %.1f] MHz\n", sample_rate / 1e6);
@@ -283,6 +287,7 @@ int main(int argc, char **argv) {
 
     cfg.n_captures = argc - first_capture;
     capture *captures = (capture *)calloc((size_t)cfg.n_captures, sizeof(capture));
+    if (!captures) return EXIT_FAILURE;
     for (int i = 0; i < cfg.n_captures; i++) {
         char *eq = strchr(argv[first_capture + i], '=');
         if (!eq) {
