@@ -53,6 +53,10 @@
 // the younger workgroup of every CU (block >= grid / 2) at a constant higher priority (the older one wins the arbitration
 // otherwise: 39 vs 53 us for the same 8 frames), levels 1, 2, 3
 #define FSEA_CFG_8192_PY1 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 38046
+// the last pass's register twiddles each gathered directly from the two factor tables (the form up to mid round 2)
+#define FSEA_CFG_8192_TWE 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 561310
+#define FSEA_CFG_4096_TWE 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 561342
+#define FSEA_CFG_1024_TWE 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 528394
 #define FSEA_CFG_8192_PPAIR 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 299166
 #define FSEA_CFG_8192_PCATCH 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 168094
 #define FSEA_CFG_4096_STATIC 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 39102

@@ -1301,17 +1301,35 @@ struct FftKernel {
                 // lanes past the end rewrite the last entry with its own value (loaded clamped above)
                 lds_all[FPW * Cfg::LDS_FRAME + (e < TAB_COPY ? e : TAB_COPY - 1)] = tabv[i];
             }
+            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) a.trace[32 * b + 28] = wall_clock64();  // tables arrived
             __syncthreads();
+            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) a.trace[32 * b + 29] = wall_clock64();  // tables in LDS
         }
+        // The last pass's register twiddles W^{r k}, k = CL tl + c, r < RL.  Each could be one product of two gathered
+        // factors, HI[m >> 6] * LO[m & 63], m = r k: 2 (RL-1) CL LDS gathers per lane, which at 8192 points keep the LDS
+        // pipe of a CU busy for 1.5 us in front of the first frame (scripts/wg_trace.py: tables in LDS at 1.6 us, twiddles
+        // built at 3.1 us).  Instead r = RB a + b: W^{r k} = W^{RB a k} * W^{b k}, so only RL/RB - 1 + RB - 1 values are
+        // gathered (10 instead of 31 at RL = 32) and the rest are products of two of those -- the same number of complex
+        // multiplies, one rounding more on the composite ones.  OPT 524288 (tuning): the direct form.
+        constexpr bool TWL_DIRECT = (Cfg::OPT & 524288) != 0;
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
         if constexpr (Cfg::TWR) {
             const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
+            auto root = [&](unsigned m) -> cf { return pk_cmul(hi[m >> 6], lo[m & 63u]); };  // W^m, m < N * RL
+            constexpr int RB = TWL_DIRECT ? RL : (RL >= 16 ? 8 : (RL >= 4 ? 2 : RL));  // low digit of r
+            constexpr int RA = RL / RB;
 #pragma unroll
-            for (int r = 1; r < RL; ++r) {
+            for (int c = 0; c < CL; ++c) {
+                const unsigned k = (unsigned)(CL * tl + c);
+                cf wb[RB], wa[RA];
 #pragma unroll
-                for (int c = 0; c < CL; ++c) {
-                    const unsigned m = (unsigned)r * (unsigned)(CL * tl + c);
-                    cf w = pk_cmul(hi[m >> 6], lo[m & 63u]);
+                for (int bb = 1; bb < RB; ++bb) wb[bb] = root((unsigned)bb * k);
+#pragma unroll
+                for (int aa = 1; aa < RA; ++aa) wa[aa] = root((unsigned)(RB * aa) * k);
+#pragma unroll
+                for (int r = 1; r < RL; ++r) {
+                    const int aa = r / RB, bb = r % RB;
+                    cf w = aa == 0 ? wb[bb] : (bb == 0 ? wa[aa] : pk_cmul(wa[aa], wb[bb]));
                     if constexpr (PRESCALED) w = w * cf{SC, SC};
                     twl[(r - 1) * CL + c] = w;
                 }
@@ -1404,6 +1422,11 @@ struct FftKernel {
             } else {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], xormask, C0 * t, v + r * C0);
+            }
+            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter == 0) {
+                // the first unit's bytes have arrived (one converted value pinned in front of the stamp)
+                asm volatile("" ::"v"(v[0]));
+                a.trace[32 * b + 30] = wall_clock64();
             }
 #pragma unroll
             for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0, MI>(v + c);

@@ -81,3 +81,9 @@ if two:
           % (lo.mean(), hi.mean(), 100 * first_faster))
     print("per CU end (last of its two workgroups): min %.2f  p50 %.2f  max %.2f us; iterations per workgroup: min %d max %d"
           % (cu_end.min(), np.median(cu_end), cu_end.max(), n_iter.min(), n_iter.max()))
+# prologue detail (tuning build): tables arrived / tables in LDS (barrier) / register twiddles built / first unit's bytes converted
+sub = (tr[:, 28:31].astype(np.int64) - tr[:, 0:1].astype(np.int64)) / 100.0
+ok = (tr[:, 28] >= tr[:, 0]) & (tr[:, 28] <= tr[:, 1])
+if ok.any():
+    print("prologue: tables arrived %.2f us, in LDS (barrier) %.2f us, register twiddles built %.2f us, first bytes converted %.2f us (means)"
+          % (sub[ok, 0].mean(), sub[ok, 1].mean(), pro[ok].mean(), sub[ok, 2].mean()))

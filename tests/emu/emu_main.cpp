@@ -158,6 +158,9 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
         EMU_VARIANT(8192, "static", FSEA_CFG_8192_STATIC)
         EMU_VARIANT(4096, "nr", FSEA_CFG_4096_LR)
         EMU_VARIANT(2048, "nr", FSEA_CFG_2048_LR)
+        EMU_VARIANT(8192, "twe", FSEA_CFG_8192_TWE)
+        EMU_VARIANT(4096, "twe", FSEA_CFG_4096_TWE)
+        EMU_VARIANT(1024, "twe", FSEA_CFG_1024_TWE)
         EMU_VARIANT(8192, "r1", FSEA_CFG_8192_R1)
         EMU_VARIANT(8192, "nd", FSEA_CFG_8192_ND)
         EMU_VARIANT(8192, "v2", FSEA_CFG_8192_V2)

@@ -115,7 +115,7 @@ def test_edge_inputs():
 
 @pytest.mark.parametrize("n,variant", [(8192, "r1"), (8192, "nd"), (8192, "v2"), (8192, "v2s"), (8192, "tk"), (8192, "pr"),
                                        (8192, "x0"), (8192, "x7"), (8192, "A"), (8192, "B"), (8192, "D"), (8192, "B2"), (8192, "D2"), (8192, "W"), (8192, "static"),
-                                       (8192, "notwl"), (8192, "notwr"), (4096, "nr"), (2048, "nr"), (4096, "x0"), (4096, "df"), (4096, "r1"), (4096, "t256"), (4096, "B3"), (4096, "B"),
+                                       (8192, "notwl"), (8192, "notwr"), (4096, "nr"), (2048, "nr"), (8192, "twe"), (4096, "twe"), (1024, "twe"), (4096, "x0"), (4096, "df"), (4096, "r1"), (4096, "t256"), (4096, "B3"), (4096, "B"),
                                        (4096, "C"), (4096, "D"), (2048, "x0"), (2048, "df"), (2048, "B"), (2048, "C"),
                                        (1024, "r1"), (1024, "x0"), (1024, "B"), (1024, "C"), (1024, "D"),
                                        (16384, "r1"), (16384, "nd"), (16384, "B"), (256, "p16"), (128, "p16")])
