@@ -1146,3 +1146,25 @@ def test_launches_can_be_captured_into_a_hip_graph():
         parity.check_mode(want[1].cpu().numpy().reshape(nf, n), iqs[1].cpu().numpy(), n, nf, n, True, 0)
         del graph
         plan.close()
+
+
+@pytest.mark.parametrize("n,nf", [(8192, 1500), (4096, 2049), (16384, 700)])
+def test_frame_distribution_does_not_change_a_bit(n, nf):
+    """Ticket pools and static interleave are two ways of handing the same frames to the workgroups: the rows are
+    identical bit for bit (every mode that has a compile-time kernel, plus the run-time-mode kernel)."""
+    iq = synth_iq(5 * n + nf, 2 * nf * n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    for mode, dt in ((0, np.float32), (2, np.uint8), (3, np.complex64)):
+        got = {}
+        for policy in (fsea.UNITS_STATIC, fsea.UNITS_TICKETS):
+            plan = fsea.Plan(n, mode=mode)
+            plan.set_unit_distribution(policy)
+            d_out = DeviceBuffer(nf * n * np.dtype(dt).itemsize)
+            plan.exec_device(d_in.ptr, nf, d_out.ptr)
+            plan.exec_device(d_in.ptr, nf, d_out.ptr)          # twice: the counters come back to zero
+            plan.synchronize()
+            got[policy] = d_out.download(dt, (nf, n))
+            d_out.free()
+            plan.close()
+        assert np.array_equal(got[fsea.UNITS_STATIC].view(np.uint8), got[fsea.UNITS_TICKETS].view(np.uint8)), (n, mode)
+    d_in.free()
