@@ -117,7 +117,13 @@ def test_gpu_stitch_equals_the_reference_binary(tmp_path):
     assert ours.shape == ref.shape == (4096, 1024) and np.array_equal(ours, ref)
 
 
-@pytest.mark.parametrize("devices,chunk", [("0", 4), ("0,0", 1), ("0,0,0", 2)])
+def _all_devices():
+    """"0-(n-1)" for the n GPUs of this box: the RCCL backend of the gather (distinct devices)."""
+    from frequensea_amd import fsea
+    return "0-%d" % (fsea.device_count() - 1)
+
+
+@pytest.mark.parametrize("devices,chunk", [("0", 4), ("0,0", 1), ("0,0,0", 2), ("all", 1), ("all", 3)])
 def test_multi_member_sweep_equals_batch_plus_stitch(tmp_path, devices, chunk):
     """fsea-fft-sweep: one host thread per member, tiles gathered chunk by chunk to member 0 and stitched
     there (RCCL between distinct GPUs; members sharing the one GPU of this box use the copy backend, same
@@ -125,6 +131,12 @@ def test_multi_member_sweep_equals_batch_plus_stitch(tmp_path, devices, chunk):
     gate included (the all-zero capture: no PNG, nothing in the image)."""
     n, rows, skip = 256, 120, 3
     freqs = [660, 665, 670, 675, 680]
+    if devices == "all":                                  # a multi-GPU box: every GPU a member, tiles over RCCL / xGMI
+        from frequensea_amd import fsea
+        if fsea.device_count() < 2:
+            pytest.skip("one GPU here: the RCCL backend needs distinct devices")
+        devices = _all_devices()
+        freqs = [660 + 5 * k for k in range(2 * fsea.device_count() + 3)]      # ragged: not a multiple of the member count
     for f in freqs:
         _capture(tmp_path / ("c%d.raw" % f), f, rows + skip, zero=(f == 670))
     caps = ["%d=%s" % (f, tmp_path / ("c%d.raw" % f)) for f in freqs]
@@ -145,7 +157,9 @@ def test_multi_member_sweep_equals_batch_plus_stitch(tmp_path, devices, chunk):
         tile = _png(ref_dir / ("broad-%d.png" % f))
         assert np.array_equal(_png(out_dir / ("broad-%d.png" % f)), tile)
         O.composite_max(want, np.ascontiguousarray(tile), k * n)
-    assert np.array_equal(_png(out_dir / "broad-stitched-660-680.png"), want)
+    assert np.array_equal(_png(out_dir / ("broad-stitched-660-%d.png" % freqs[-1])), want)
+    if "-" in devices:
+        assert "Gather backend: rccl" in res.stdout
 
 
 def test_multi_member_narrow_sweep_with_overlap(tmp_path):
