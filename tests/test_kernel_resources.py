@@ -1,0 +1,89 @@
+"""CPU tier: the resource usage of every kernel in the shipped libfsea_hip.so, read from the code objects' own
+metadata (the clang offload bundle inside the library -> gfx950 ELF -> NT_AMDGPU_METADATA note).  A register spill or
+a scratch allocation in a hot kernel is a silent 5-10 % (it happened once during round 2: a change that moved the
+twiddle build into the loop cost 11-25 spilled VGPRs); this pins the budget so that a build that regresses fails here,
+without a GPU."""
+import os
+import struct
+
+import msgpack
+import pytest
+
+from tests.conftest import ROOT
+
+LIB = os.path.join(ROOT, "frequensea_amd", "libfsea_hip.so")
+SIZES = (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384)
+KINDS = ("u8_mag", "u8_db5", "u8_db10", "u8", "u8_rot", "f32")
+
+
+def _kernels(path):
+    data = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out = {}
+    pos = data.find(magic)
+    while pos >= 0:
+        count = struct.unpack_from("<Q", data, pos + 24)[0]
+        off = pos + 32
+        for _ in range(count):
+            o, size, tlen = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24: off + 24 + tlen].decode()
+            off += 24 + tlen
+            if "gfx950" not in triple or size == 0:
+                continue
+            elf = data[pos + o: pos + o + size]
+            shoff = struct.unpack_from("<Q", elf, 0x28)[0]
+            shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+            for i in range(shnum):
+                sh = shoff + i * shentsize
+                if struct.unpack_from("<I", elf, sh + 4)[0] != 7:          # SHT_NOTE
+                    continue
+                s_off, s_size = struct.unpack_from("<QQ", elf, sh + 0x18)
+                p = s_off
+                while p < s_off + s_size:
+                    namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+                    name = elf[p + 12: p + 12 + namesz].rstrip(b"\0")
+                    d0 = p + 12 + ((namesz + 3) & ~3)
+                    if name == b"AMDGPU" and ntype == 32:                   # NT_AMDGPU_METADATA
+                        for k in msgpack.unpackb(elf[d0: d0 + descsz], raw=False)["amdhsa.kernels"]:
+                            out[k[".name"]] = k
+                    p = d0 + ((descsz + 3) & ~3)
+        pos = data.find(magic, pos + 1)
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(LIB):
+        pytest.skip("libfsea_hip.so not built")
+    ks = _kernels(LIB)
+    assert ks, "no gfx950 code object found in libfsea_hip.so"
+    return ks
+
+
+def test_every_size_has_its_six_entry_points_and_nothing_experimental(kernels):
+    fft = sorted(k for k in kernels if k.startswith("fsea_fft"))
+    assert fft == sorted("fsea_fft%d_%s" % (n, kind) for n in SIZES for kind in KINDS)
+    assert not [k for k in kernels if "abl" in k]
+
+
+def test_hot_kernels_do_not_spill(kernels):
+    for n in SIZES:
+        for kind in KINDS:
+            k = kernels["fsea_fft%d_%s" % (n, kind)]
+            assert k[".vgpr_count"] <= 256 and k[".wavefront_size"] == 64
+            if kind == "f32":
+                # the f32-complex input branch (NUT_BUFFER_F64, one frame per call) prefetches 64 VGPRs of rows: a few
+                # spilled registers at two sizes are accepted there, not more
+                assert k[".vgpr_spill_count"] <= 16 and k[".private_segment_fixed_size"] <= 64, (n, kind)
+            else:
+                assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, (n, kind, k[".vgpr_spill_count"])
+
+
+def test_occupancy_budget_of_the_multi_wave_sizes(kernels):
+    """Two workgroups per CU at 4096 and 8192 points (LDS <= 80 KB each, <= 256 VGPRs at 2 waves per SIMD), one at 16384."""
+    for n, lds_max in ((4096, 80 * 1024), (8192, 80 * 1024), (16384, 160 * 1024)):
+        for kind in KINDS:
+            k = kernels["fsea_fft%d_%s" % (n, kind)]
+            assert k[".group_segment_fixed_size"] <= lds_max, (n, kind)
+    assert kernels["fsea_fft8192_u8_mag"][".max_flat_workgroup_size"] == 256
+    assert kernels["fsea_fft16384_u8_mag"][".max_flat_workgroup_size"] == 512
