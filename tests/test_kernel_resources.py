@@ -87,3 +87,30 @@ def test_occupancy_budget_of_the_multi_wave_sizes(kernels):
             assert k[".group_segment_fixed_size"] <= lds_max, (n, kind)
     assert kernels["fsea_fft8192_u8_mag"][".max_flat_workgroup_size"] == 256
     assert kernels["fsea_fft16384_u8_mag"][".max_flat_workgroup_size"] == 512
+
+
+def test_libraries_link_no_fft_or_blas_library():
+    """The transform is this repository's own kernels: nothing in the dynamic dependencies of the shipped libraries
+    (or of the tools) that could compute an FFT or a GEMM for them -- no rocFFT / hipFFT / hipfftw / rocBLAS / hipBLASLt /
+    MIOpen, and RCCL only in the multi-GPU gather library."""
+    import subprocess
+    pkg = os.path.join(ROOT, "frequensea_amd")
+    files = [os.path.join(pkg, f) for f in ("libfsea_hip.so", "libfsea_nrf.so", "libfsea_nrf_fft.so", "libfsea_rccl.so")]
+    files += [os.path.join(pkg, "bin", f) for f in ("fsea-fft-batch", "fsea-fft-stitch", "fsea-fft-sweep", "fsea-add-markers")]
+    banned = ("fft", "blas", "miopen", "rocsolver", "rocsparse", "mkl", "torch")
+    for path in files:
+        if not os.path.exists(path):
+            pytest.skip("not built: " + path)
+        out = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, check=True).stdout
+        needed = [ln.split("[")[1].split("]")[0].lower() for ln in out.splitlines() if "(NEEDED)" in ln]
+        assert needed, path
+        for lib in needed:
+            assert not any(b in lib for b in banned if not lib.startswith("libfsea")), (path, lib)
+            if lib.startswith("librccl"):                  # RCCL itself: only the gather library links it
+                assert os.path.basename(path) == "libfsea_rccl.so", (path, lib)
+            if lib == "libfsea_rccl.so":                   # and only the multi-GPU tool links that
+                assert os.path.basename(path) == "fsea-fft-sweep", (path, lib)
+    # and the product library does not reach the oracle
+    for path in files:
+        out = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, check=True).stdout
+        assert "oracle" not in out.lower()
