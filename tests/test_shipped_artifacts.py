@@ -114,3 +114,34 @@ def test_libraries_link_no_fft_or_blas_library():
     for path in files:
         out = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, check=True).stdout
         assert "oracle" not in out.lower()
+
+
+def test_the_oracle_is_reachable_from_the_checkers_only():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import,
+    link or run it.  No source file of the product (frequensea_amd/, include/) names it in code, bench.py imports it in
+    one function only, and that function feeds cpu_baseline and nothing else."""
+    import ast
+    import re
+    pkg = os.path.join(ROOT, "frequensea_amd")
+    for dirpath, _, names in os.walk(pkg):
+        if "build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for name in names:
+            if not name.endswith((".py", ".c", ".h", ".hip", ".cpp")) and name != "Makefile":
+                continue
+            text = open(os.path.join(dirpath, name), errors="replace").read()
+            code = re.sub(r'""".*?"""|/\\*.*?\\*/|//[^\\n]*|#[^\\n]*', "", text, flags=re.S)   # comments and docstrings may mention it
+            assert "oracle" not in code.lower(), os.path.join(dirpath, name)
+    for name in os.listdir(os.path.join(ROOT, "include")):
+        text = open(os.path.join(ROOT, "include", name)).read()
+        assert not re.search(r'#\\s*include\\s*[<"][^>"]*oracle', text), name
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    importers = []
+    for fn in ast.walk(tree):
+        if isinstance(fn, ast.FunctionDef):
+            for node in ast.walk(fn):
+                if isinstance(node, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(node):
+                    importers.append(fn.name)
+    assert importers == ["cpu_baseline"], importers
+    for node in tree.body:                                   # and no module-level import of it
+        assert not (isinstance(node, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(node))
