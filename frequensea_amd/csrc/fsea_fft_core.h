@@ -385,6 +385,33 @@ typedef uint32_t u32x4 __attribute__((vector_size(16)));
 __device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 
+// 16-byte stores and the registers they read.  A VALU instruction that overwrites a data register of a
+// buffer_store_dwordx4 too soon behind it corrupts what the store writes: the store reads its four registers over
+// several cycles, a quarter of each 16-lane row at a time, and lanes 12-15 of every row come last.  The compiler knows
+// the hazard (LLVM's VmemStoreHazard) and keeps two wait states for gfx940-class targets; on the MI355X that is one too
+// few when the CU is busy -- rows of the 64-, 128- and 2048-point kernels (four adjacent f32 bins per lane) differed
+// between identical launches in lanes 12-15 of a row, first register of the quad, beyond the first unit of the
+// first-placed workgroups (scripts/soak.py found it; profiles/r02_store_data_hazard.txt).  One more wait state cures
+// it; eight are spent here, fenced so that the scheduler cannot move the next writer in front of them.
+// FSEA_STORE_GUARD: 1 = that (default), 0 = nothing (the pre-fix code, for the regression evidence), 2 = two 8-byte
+// stores instead (no hazard by construction; 3-20 % slower at those sizes).
+#ifndef FSEA_STORE_GUARD
+#define FSEA_STORE_GUARD 1
+#endif
+__device__ __forceinline__ void store_data_guard() {
+#if !defined(__AMDGCN__)
+    // (the CPU shim of tests/emu compiles this header too: nothing to guard there)
+#elif FSEA_STORE_GUARD == 1
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7");
+    __builtin_amdgcn_sched_barrier(0);
+#elif FSEA_STORE_GUARD >= 10 /* experiment: FSEA_STORE_GUARD - 10 = operand of a single s_nop */
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop %0" ::"n"(FSEA_STORE_GUARD - 10));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // C consecutive f32 / u8 / complex outputs at byte offset voff (+ scalar soff)
 // AUX: cache-policy bits of the buffer instruction (0 = default, 2 = nt: streaming, do not keep)
 template <int C, int AUX = 0>
@@ -396,8 +423,14 @@ __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, con
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
+#if FSEA_STORE_GUARD == 2
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c]), f2u(v[c + 1])}, rs, voff + 4 * c, soff, AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c + 2]), f2u(v[c + 3])}, rs, voff + 4 * c + 8, soff, AUX);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c]), f2u(v[c + 1]), f2u(v[c + 2]), f2u(v[c + 3])}, rs,
                                                    voff + 4 * c, soff, AUX);
+            store_data_guard();
+#endif
         }
     }
 }
@@ -425,8 +458,14 @@ __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, con
     } else {
 #pragma unroll
         for (int c = 0; c < C; c += 2) {
+#if FSEA_STORE_GUARD == 2
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c][0]), f2u(v[c][1])}, rs, voff + 8 * c, soff, AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c + 1][0]), f2u(v[c + 1][1])}, rs, voff + 8 * c + 8, soff, AUX);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c][0]), f2u(v[c][1]), f2u(v[c + 1][0]), f2u(v[c + 1][1])},
                                                    rs, voff + 8 * c, soff, AUX);
+            store_data_guard();
+#endif
         }
     }
 }
@@ -858,42 +897,53 @@ struct FftKernel {
                 }
                 if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + CL, soff, px + (CL - 1));
             }
+        } else if (mode == MODE_DB_F32) {
+            // two loops, one transcendental each: written as `mode == MODE_DB_F32 ? log : sqrt` per element the compiler
+            // turns the uniform test into v_log_f32 + v_sqrt_f32 + v_cndmask for every bin
+            f32_rows<true>(patched, out, lane_elem, v, t);
         } else {
-            const uint32_t voff = lane_elem * 4u;
-            [[maybe_unused]] float wide[4];
+            f32_rows<false>(patched, out, lane_elem, v, t);
+        }
+    }
+
+    template <bool LOG>
+    static __device__ __forceinline__ void f32_rows(bool patched, rsrc_t out, uint32_t lane_elem, cf *v, int t) {
+        constexpr float SE = PRESCALED ? 1.0f : SC;
+        constexpr float SE2 = SE * SE;
+        const uint32_t voff = lane_elem * 4u;
+        [[maybe_unused]] float wide[4];
 #pragma unroll
-            for (int r = 0; r < RL; ++r) {
-                const uint32_t soff = (uint32_t)(r * NsL) * 4u;
-                float m[CL];
+        for (int r = 0; r < RL; ++r) {
+            const uint32_t soff = (uint32_t)(r * NsL) * 4u;
+            float m[CL];
 #pragma unroll
-                for (int c = 0; c < CL; ++c) {
-                    const cf z = v[r * CL + c];
-                    float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
-                    if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
-                    if (mode == MODE_DB_F32) {
-                        m[c] = (10.0f * 0.30102999566398120f) * __builtin_amdgcn_logf(p + 1.0e-20f);
-                    } else if constexpr (Cfg::ABL & 128) {  // ABL 128 (measurement only): no magnitude arithmetic
-                        m[c] = z[0];
-                    } else {
-                        m[c] = __builtin_amdgcn_sqrtf(p);
-                    }
-                }
-                if constexpr (Cfg::ABL & 1) {
-                    if (m[0] == -1.0f) bst<CL>(out, voff, soff, m);  // never true: sqrt >= 0
-                } else if constexpr ((Cfg::ABL & 256) != 0 && CL == 1 && RL % 4 == 0) {
-                    // ABL 256 (measurement only, bins land in the wrong places): the row stored 16 bytes per
-                    // lane, 1 KiB runs per wave instruction -- what a last pass with 4 adjacent bins per lane
-                    // would issue.  The values wait in wide[] until four are there.
-                    wide[r & 3] = m[0];
-                    if ((r & 3) == 3) bst<4, ST_AUX>(out, (lane_elem + 3u * (uint32_t)t) * 4u, (uint32_t)((r >> 2) * 4 * T) * 4u, wide);
-                } else if (patched && r == RL / 2 && t == 0) {
-#pragma unroll
-                    for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);
+            for (int c = 0; c < CL; ++c) {
+                const cf z = v[r * CL + c];
+                float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
+                if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
+                if constexpr (LOG) {
+                    m[c] = (10.0f * 0.30102999566398120f) * __builtin_amdgcn_logf(p + 1.0e-20f);
+                } else if constexpr (Cfg::ABL & 128) {  // ABL 128 (measurement only): no magnitude arithmetic
+                    m[c] = z[0];
                 } else {
-                    bst<CL, st_aux<4>()>(out, voff, soff, m);
+                    m[c] = __builtin_amdgcn_sqrtf(p);
                 }
-                if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + 4 * CL, soff, m + (CL - 1));
             }
+            if constexpr (Cfg::ABL & 1) {
+                if (m[0] == -1.0f) bst<CL>(out, voff, soff, m);  // never true: sqrt >= 0
+            } else if constexpr ((Cfg::ABL & 256) != 0 && CL == 1 && RL % 4 == 0) {
+                // ABL 256 (measurement only, bins land in the wrong places): the row stored 16 bytes per
+                // lane, 1 KiB runs per wave instruction -- what a last pass with 4 adjacent bins per lane
+                // would issue.  The values wait in wide[] until four are there.
+                wide[r & 3] = m[0];
+                if ((r & 3) == 3) bst<4, ST_AUX>(out, (lane_elem + 3u * (uint32_t)t) * 4u, (uint32_t)((r >> 2) * 4 * T) * 4u, wide);
+            } else if (patched && r == RL / 2 && t == 0) {
+#pragma unroll
+                for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);
+            } else {
+                bst<CL, st_aux<4>()>(out, voff, soff, m);
+            }
+            if (patched && r == RL / 2 - 1 && t == T - 1) bst<1>(out, voff + 4 * CL, soff, m + (CL - 1));
         }
     }
 

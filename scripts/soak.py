@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Soak run: minutes of randomly drawn launches (size, mode, frame count, hop, byte convention, frame distribution,
+one of four streams, plain / tiled / frequency-shifted entry point), every one checked on sampled rows against numpy.
+Looks for what the unit tests cannot: rare interleavings of overlapping launches, ticket-counter residue, hangs.
+Usage: python scripts/soak.py [seconds, default 120] [seed]"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from frequensea_amd import fsea  # noqa: E402
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+L = fsea.hip_lib()
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+streams = [ctypes.c_void_p() for _ in range(4)]
+for s in streams:
+    assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+MAX_IN = 1 << 27                                   # bytes of IQ per launch at most
+host = rng.integers(-100, 100, MAX_IN + (1 << 16), dtype=np.int8).view(np.uint8)
+
+
+def dev_alloc(nbytes):
+    p = ctypes.c_void_p()
+    fsea._check(L.fsea_device_alloc(0, nbytes, ctypes.byref(p)))
+    return p
+
+
+d_in = dev_alloc(host.nbytes)
+fsea._check(L.fsea_copy_to_device(0, d_in, host.ctypes.data, host.nbytes))
+d_out = [dev_alloc(4 * MAX_IN) for _ in streams]   # f32 rows of a non-overlapped launch fit; others are clipped below
+plans = {}
+
+
+def rows_numpy(offset_bytes, frame, n, hop, flip, mode):
+    raw = host[offset_bytes + 2 * frame * hop: offset_bytes + 2 * frame * hop + 2 * n]
+    u = (raw ^ np.uint8(0x80 if flip else 0)).astype(np.float64).reshape(n, 2) / 256.0
+    x = (u[:, 0] + 1j * u[:, 1]) * (1.0 - 2.0 * (np.arange(n) & 1))
+    X = np.fft.fft(x)
+    mag = np.abs(X)
+    if mode == 0:
+        mag[n // 2] = mag[n // 2 - 1]
+        return mag
+    if mode == 3:
+        return X
+    if mode == 4:
+        return mag
+    if mode == 5:
+        return 10.0 * np.log10(mag * mag + 1e-20)
+    p = mag * mag
+    k = 100.0 if mode == 1 else 50.0
+    px = np.clip((k * np.log10(p + 1e-20)).astype(np.int64), 0, 255)
+    if mode == 2:
+        px[n // 2] = px[n // 2 - 1]
+    return px
+
+
+t_end = time.time() + SECONDS
+launches = checked = 0
+pending = [None] * len(streams)
+while time.time() < t_end:
+    si = int(rng.integers(len(streams)))
+    if pending[si] is not None:                    # verify what this stream ran last, then reuse its buffer
+        assert hip.hipStreamSynchronize(streams[si]) == 0
+        n, nf, hop, flip, mode, off, tiled, shape = pending[si]
+        dt = {0: np.float32, 1: np.uint8, 2: np.uint8, 3: np.complex64, 4: np.float32, 5: np.float32}[mode]
+        for f in sorted({0, nf - 1, int(rng.integers(nf))}):
+            row = np.empty(n, dt)
+            if tiled:
+                rows_t, stride, first_x, step = shape
+                k, y = divmod(f, rows_t)
+                src = d_out[si].value + (y * stride + first_x + k * step) * row.itemsize
+            else:
+                src = d_out[si].value + f * n * row.itemsize
+            fsea._check(L.fsea_copy_to_host(0, row.ctypes.data, ctypes.c_void_p(src), row.nbytes))
+            want = rows_numpy(off, f, n, hop, flip, mode)
+            if mode in (1, 2):
+                # f32 transform against an f64 reference: a pixel on a truncation boundary may land one level off
+                # (SURVEY 8(c)); on a single row that is a handful of pixels, never more than one level
+                delta = np.abs(row.astype(np.int32) - want.astype(np.int32))
+                assert delta.max() <= 1 and (delta != 0).sum() <= max(3, n // 100), (n, nf, hop, flip, mode, f, int(delta.max()), int((delta != 0).sum()))
+            else:
+                if mode == 5:                      # dB rows: absolute error (0.01 dB), not relative to the row's norm
+                    err = float(np.abs(row - want)[want > -150].max())
+                    assert err < 1e-2, (n, nf, hop, flip, mode, f, err)
+                else:
+                    rel = np.linalg.norm(row - want) / max(np.linalg.norm(want), 1e-30)
+                    assert rel < 2e-6, (n, nf, hop, flip, mode, f, rel)
+            checked += 1
+        pending[si] = None
+    n = int(rng.choice(SIZES))
+    mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5]))
+    hop = n if rng.random() < 0.7 else int(rng.choice([n // 2, n // 4, 2 * n, 8]))
+    hop = max(8, hop - hop % 8)
+    esz = {0: 4, 1: 1, 2: 1, 3: 8, 4: 4, 5: 4}[mode]
+    nf_max = min((MAX_IN - 2 * n) // (2 * hop) + 1, (4 * MAX_IN) // (esz * n))
+    nf = int(min(nf_max, rng.choice([1, 2, 3, 7, 64, 511, 4096, 20000, 70000])))
+    flip = bool(rng.integers(2))
+    off = 16 * int(rng.integers(0, 2048))
+    key = (n, hop, mode)
+    if key not in plans:
+        plans[key] = fsea.Plan(n, hop=hop, mode=mode)
+    plan = plans[key]
+    plan.set_unit_distribution(int(rng.integers(3)))
+    tiled, shape = False, None
+    if hop == n and rng.random() < 0.2:            # rows into an image, tiles side by side
+        fpw = 1 if n >= 8192 else 2 if n == 4096 else 4 if n == 2048 else 8 if n == 1024 else 16 if n == 512 else 64
+        rows_t = fpw * int(rng.integers(1, 4))
+        tiles = max(1, min(nf // rows_t, 6))
+        nf = tiles * rows_t
+        step, first_x = n + 4 * int(rng.integers(0, 3)), 4 * int(rng.integers(0, 5))
+        stride = first_x + (tiles - 1) * step + n + 8
+        tiled, shape = True, (rows_t, stride, first_x, step)
+        plan.exec_tiled_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], rows_t + 1, stride, first_x, rows_t, step,
+                               flip=flip, stream=streams[si].value)
+    else:
+        plan.exec_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], flip=flip, stream=streams[si].value)
+    pending[si] = (n, nf, hop, flip, mode, off, tiled, shape)
+    launches += 1
+for s in streams:
+    assert hip.hipStreamSynchronize(s) == 0
+print("soak: %.0f s, %d launches on %d streams, %d plans, %d rows checked against numpy, no mismatch, no hang"
+      % (SECONDS, launches, len(streams), len(plans), checked))

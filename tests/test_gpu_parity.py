@@ -1168,3 +1168,35 @@ def test_frame_distribution_does_not_change_a_bit(n, nf):
             plan.close()
         assert np.array_equal(got[fsea.UNITS_STATIC].view(np.uint8), got[fsea.UNITS_TICKETS].view(np.uint8)), (n, mode)
     d_in.free()
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_identical_launches_give_identical_rows_under_load(n):
+    """Long launches (every CU holds its full complement of workgroups) of the run-time-mode kernel in the f32-row modes,
+    three times each: the rows must not differ between identical launches, and sampled rows must match the oracle.
+    Regression test for a rare corruption found by scripts/soak.py (round 2): with `mode == DB_F32 ? log : sqrt` per
+    element the compiler emitted v_log_f32 + v_sqrt_f32 + v_cndmask, and under load lanes 12-15 of every 16-lane row
+    sometimes kept a stale value -- visible only at 128 and 2048 points (four adjacent bins per lane in the last pass)
+    and only beyond the first unit of the first-placed workgroups, so that no short test had ever seen it."""
+    nf = max(2000, (40000 * 128) // n) if n <= 2048 else 6000
+    iq = synth_iq(40 + n, 2 * nf * n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_out = DeviceBuffer(nf * n * 4)
+    rng = np.random.default_rng(n)
+    for mode, flip in ((fsea.MODE_MAG_F32, False), (fsea.MODE_MAG_NODC_F32, True), (fsea.MODE_DB_F32, True)):
+        plan = fsea.Plan(n, mode=mode)
+        outs = []
+        for rep in range(3):
+            plan.exec_device(d_in.ptr, nf, d_out.ptr, flip=flip)
+            plan.synchronize()
+            outs.append(d_out.download(np.float32, (nf, n)))
+        for o in outs[1:]:
+            differing = np.nonzero((outs[0].view(np.uint32) != o.view(np.uint32)).any(axis=1))[0]
+            assert differing.size == 0, (n, mode, differing[:8])
+        rows = sorted({0, nf - 1, *rng.integers(nf // 2, nf, 5)})
+        for f in rows:
+            f = int(f)
+            parity.check_mode(outs[0][f:f + 1], iq[2 * f * n: 2 * (f + 1) * n], n, 1, n, flip, mode)
+        plan.close()
+    d_in.free()
+    d_out.free()
