@@ -40,10 +40,14 @@ d_out = [dev_alloc(4 * MAX_IN) for _ in streams]   # f32 rows of a non-overlappe
 plans = {}
 
 
-def rows_numpy(offset_bytes, frame, n, hop, flip, mode):
+def rows_numpy(offset_bytes, frame, n, hop, flip, mode, shift=None):
     raw = host[offset_bytes + 2 * frame * hop: offset_bytes + 2 * frame * hop + 2 * n]
     u = (raw ^ np.uint8(0x80 if flip else 0)).astype(np.float64).reshape(n, 2) / 256.0
-    x = (u[:, 0] + 1j * u[:, 1]) * (1.0 - 2.0 * (np.arange(n) & 1))
+    y = u[:, 0] + 1j * u[:, 1]
+    if shift is not None:                          # fsea.h: y[m] = (u8[m]/256) e^{2 pi i (phase0 + m delta)} + 0.5 (1 + i)
+        m_idx = frame * hop + np.arange(n)
+        y = y * np.exp(2j * np.pi * (shift[1] + m_idx * shift[0])) + 0.5 * (1 + 1j)
+    x = y * (1.0 - 2.0 * (np.arange(n) & 1))
     X = np.fft.fft(x)
     mag = np.abs(X)
     if mode == 0:
@@ -70,7 +74,7 @@ while time.time() < t_end:
     si = int(rng.integers(len(streams)))
     if pending[si] is not None:                    # verify what this stream ran last, then reuse its buffer
         assert hip.hipStreamSynchronize(streams[si]) == 0
-        n, nf, hop, flip, mode, off, tiled, shape = pending[si]
+        n, nf, hop, flip, mode, off, tiled, shape, shift = pending[si]
         dt = {0: np.float32, 1: np.uint8, 2: np.uint8, 3: np.complex64, 4: np.float32, 5: np.float32}[mode]
         for f in sorted({0, nf - 1, int(rng.integers(nf))}):
             row = np.empty(n, dt)
@@ -81,7 +85,9 @@ while time.time() < t_end:
             else:
                 src = d_out[si].value + f * n * row.itemsize
             fsea._check(L.fsea_copy_to_host(0, row.ctypes.data, ctypes.c_void_p(src), row.nbytes))
-            want = rows_numpy(off, f, n, hop, flip, mode)
+            want = rows_numpy(off, f, n, hop, flip, mode, shift)
+            if shift is not None and mode in (0, 2):   # the restored offset sits in bin N/2, which these modes overwrite
+                pass
             if mode in (1, 2):
                 # f32 transform against an f64 reference: a pixel on a truncation boundary may land one level off
                 # (SURVEY 8(c)); on a single row that is a handful of pixels, never more than one level
@@ -110,8 +116,12 @@ while time.time() < t_end:
         plans[key] = fsea.Plan(n, hop=hop, mode=mode)
     plan = plans[key]
     plan.set_unit_distribution(int(rng.integers(3)))
-    tiled, shape = False, None
-    if hop == n and rng.random() < 0.2:            # rows into an image, tiles side by side
+    tiled, shape, shift = False, None, None
+    if rng.random() < 0.12:                        # the frequency shifter fused into the load (fsea_exec_u8_shifted_device)
+        shift = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0, 1)))
+        plan.exec_shifted_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], shift[0], shift[1], flip=flip,
+                                 stream=streams[si].value)
+    elif hop == n and rng.random() < 0.2:            # rows into an image, tiles side by side
         fpw = 1 if n >= 8192 else 2 if n == 4096 else 4 if n == 2048 else 8 if n == 1024 else 16 if n == 512 else 64
         rows_t = fpw * int(rng.integers(1, 4))
         tiles = max(1, min(nf // rows_t, 6))
@@ -123,7 +133,7 @@ while time.time() < t_end:
                                flip=flip, stream=streams[si].value)
     else:
         plan.exec_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], flip=flip, stream=streams[si].value)
-    pending[si] = (n, nf, hop, flip, mode, off, tiled, shape)
+    pending[si] = (n, nf, hop, flip, mode, off, tiled, shape, shift)
     launches += 1
 for s in streams:
     assert hip.hipStreamSynchronize(s) == 0
