@@ -94,9 +94,10 @@ while time.time() < t_end:
                 delta = np.abs(row.astype(np.int32) - want.astype(np.int32))
                 assert delta.max() <= 1 and (delta != 0).sum() <= max(3, n // 100), (n, nf, hop, flip, mode, f, int(delta.max()), int((delta != 0).sum()))
             else:
-                if mode == 5:                      # dB rows: absolute error (0.01 dB), not relative to the row's norm
-                    err = float(np.abs(row - want)[want > -150].max())
-                    assert err < 1e-2, (n, nf, hop, flip, mode, f, err)
+                if mode == 5:                      # dB rows: back to magnitudes, then the same relative-L2 bound
+                    got_mag, want_mag = 10.0 ** (row.astype(np.float64) / 20.0), 10.0 ** (want / 20.0)
+                    rel = np.linalg.norm(got_mag - want_mag) / max(np.linalg.norm(want_mag), 1e-30)
+                    assert rel < 4e-6, (n, nf, hop, flip, mode, f, rel)
                 else:
                     rel = np.linalg.norm(row - want) / max(np.linalg.norm(want), 1e-30)
                     assert rel < 2e-6, (n, nf, hop, flip, mode, f, rel)
