@@ -1181,17 +1181,19 @@ def test_identical_launches_give_identical_rows_under_load(n):
     nf = max(2000, (40000 * 128) // n) if n <= 2048 else 6000
     iq = synth_iq(40 + n, 2 * nf * n)
     d_in = DeviceBuffer(iq.nbytes).upload(iq)
-    d_out = DeviceBuffer(nf * n * 4)
+    d_out = DeviceBuffer(nf * n * 8)
     rng = np.random.default_rng(n)
-    for mode, flip in ((fsea.MODE_MAG_F32, False), (fsea.MODE_MAG_NODC_F32, True), (fsea.MODE_DB_F32, True)):
+    for mode, flip in ((fsea.MODE_MAG_F32, False), (fsea.MODE_MAG_NODC_F32, True), (fsea.MODE_DB_F32, True),
+                       (fsea.MODE_COMPLEX_F32, True)):                 # complex rows: 16-byte stores at most sizes
         plan = fsea.Plan(n, mode=mode)
+        dt = np.complex64 if mode == fsea.MODE_COMPLEX_F32 else np.float32
         outs = []
         for rep in range(3):
             plan.exec_device(d_in.ptr, nf, d_out.ptr, flip=flip)
             plan.synchronize()
-            outs.append(d_out.download(np.float32, (nf, n)))
+            outs.append(d_out.download(dt, (nf, n)))
         for o in outs[1:]:
-            differing = np.nonzero((outs[0].view(np.uint32) != o.view(np.uint32)).any(axis=1))[0]
+            differing = np.nonzero((outs[0].view(np.uint32).reshape(nf, -1) != o.view(np.uint32).reshape(nf, -1)).any(axis=1))[0]
             assert differing.size == 0, (n, mode, differing[:8])
         rows = sorted({0, nf - 1, *rng.integers(nf // 2, nf, 5)})
         for f in rows:
