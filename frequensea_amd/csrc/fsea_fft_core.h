@@ -391,8 +391,11 @@ __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(flo
 // the hazard (LLVM's VmemStoreHazard) and keeps two wait states for gfx940-class targets; on the MI355X that is one too
 // few when the CU is busy -- rows of the 64-, 128- and 2048-point kernels (four adjacent f32 bins per lane) differed
 // between identical launches in lanes 12-15 of a row, first register of the quad, beyond the first unit of the
-// first-placed workgroups (scripts/soak.py found it; profiles/r02_store_data_hazard.txt).  One more wait state cures
-// it; eight are spent here, fenced so that the scheduler cannot move the next writer in front of them.
+// first-placed workgroups (scripts/soak.py found it; profiles/r02_store_data_hazard.txt).  In isolation the hardware needs
+// two wait states (scripts/ubench/store_data_hazard.hip: none -> 23 % of the stores wrong, one -> 0.8 %, two -> none); next
+// to a wave that keeps the register file busy with packed FMAs it needs a third.  Sixteen are spent here (five times what
+// was ever seen to be needed; the wave only idles while its neighbour works), fenced so that the scheduler cannot move the
+// next writer in front of them.
 // FSEA_STORE_GUARD: 1 = that (default), 0 = nothing (the pre-fix code, for the regression evidence), 2 = two 8-byte
 // stores instead (no hazard by construction; 3-20 % slower at those sizes).
 #ifndef FSEA_STORE_GUARD
@@ -403,7 +406,7 @@ __device__ __forceinline__ void store_data_guard() {
     // (the CPU shim of tests/emu compiles this header too: nothing to guard there)
 #elif FSEA_STORE_GUARD == 1
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7");
+    asm volatile("s_nop 7\n\ts_nop 7");
     __builtin_amdgcn_sched_barrier(0);
 #elif FSEA_STORE_GUARD >= 10 /* experiment: FSEA_STORE_GUARD - 10 = operand of a single s_nop */
     __builtin_amdgcn_sched_barrier(0);
