@@ -1202,3 +1202,24 @@ def test_identical_launches_give_identical_rows_under_load(n):
         plan.close()
     d_in.free()
     d_out.free()
+
+
+@pytest.mark.parametrize("n,nf", [(128, 40000), (2048, 6000), (4096, 3000), (16384, 700)])
+def test_f64_input_rows_are_repeatable_under_load(n, nf):
+    """The f32-complex kernels (NUT_BUFFER_F64 input) on launches long enough to load every CU: identical calls give
+    identical rows, and sampled rows match numpy (same reason as test_identical_launches_give_identical_rows_under_load;
+    these kernels hold 16-byte stores at 128 and 2048 points too)."""
+    rng = np.random.default_rng(n)
+    x = rng.normal(0, 0.2, 2 * nf * n)
+    plan = fsea.Plan(n)
+    outs = [plan.exec_host_f64(x, nf) for _ in range(3)]
+    for o in outs[1:]:
+        differing = np.nonzero((outs[0].view(np.uint32) != o.view(np.uint32)).any(axis=1))[0]
+        assert differing.size == 0, (n, differing[:8])
+    for f in sorted({0, nf - 1, *rng.integers(nf // 2, nf, 4)}):
+        f = int(f)
+        z = (x[2 * f * n: 2 * (f + 1) * n: 2] + 1j * x[2 * f * n + 1: 2 * (f + 1) * n: 2]) * (1.0 - 2.0 * (np.arange(n) & 1))
+        want = np.abs(np.fft.fft(z))
+        want[n // 2] = want[n // 2 - 1]
+        assert np.linalg.norm(outs[0][f] - want) / np.linalg.norm(want) < 1e-6, (n, f)
+    plan.close()
