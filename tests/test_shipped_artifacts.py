@@ -145,3 +145,52 @@ def test_the_oracle_is_reachable_from_the_checkers_only():
     assert importers == ["cpu_baseline"], importers
     for node in tree.body:                                   # and no module-level import of it
         assert not (isinstance(node, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(node))
+
+
+def _code_objects(path):
+    data = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    pos = data.find(magic)
+    while pos >= 0:
+        count = struct.unpack_from("<Q", data, pos + 24)[0]
+        off = pos + 32
+        for _ in range(count):
+            o, size, tlen = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24: off + 24 + tlen].decode()
+            off += 24 + tlen
+            if "gfx950" in triple and size:
+                yield data[pos + o: pos + o + size]
+        pos = data.find(magic, pos + 1)
+
+
+def test_every_16_byte_store_is_followed_by_its_wait_states(tmp_path):
+    """DESIGN.md section 3, the store-data hazard: a VALU write to a data register of a 16-byte store too soon behind it
+    changes what the store writes.  Every such store in the shipped kernels must be followed by the fenced wait states of
+    store_data_guard() (two `s_nop 7`) before the next vector instruction -- checked in the disassembly of the code
+    objects inside libfsea_hip.so, so that a 16-byte store added past `bst` fails here without a GPU."""
+    import re
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump) or not os.path.exists(LIB):
+        pytest.skip("llvm-objdump or libfsea_hip.so not available")
+    stores = 0
+    for i, elf in enumerate(_code_objects(LIB)):
+        path = tmp_path / ("co%d.elf" % i)
+        path.write_bytes(elf)
+        text = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(path)], capture_output=True, text=True, check=True).stdout
+        lines = [ln.split("//")[0].strip() for ln in text.splitlines()]
+        lines = [ln for ln in lines if ln and not ln.endswith(":") and not ln.startswith(("Disassembly", "/"))]
+        for k, ln in enumerate(lines):
+            if not re.match(r"(buffer|global|flat|scratch)_store_dwordx[34]\b", ln):
+                continue
+            stores += 1
+            waits = 0
+            for nxt in lines[k + 1: k + 8]:
+                m = re.match(r"s_nop (\d+)", nxt)
+                if m:
+                    waits += int(m.group(1)) + 1
+                    continue
+                if nxt.startswith(("v_", "ds_", "buffer_", "global_")):
+                    break
+            assert waits >= 8, "16-byte store without its wait states: %r followed by %r" % (ln, lines[k + 1: k + 4])
+    assert stores > 50        # the 64-, 128- and 2048-point f32 rows and the complex rows do use them
