@@ -92,15 +92,16 @@ while time.time() < t_end:
                 # f32 transform against an f64 reference: a pixel on a truncation boundary may land one level off
                 # (SURVEY 8(c)); on a single row that is a handful of pixels, never more than one level
                 delta = np.abs(row.astype(np.int32) - want.astype(np.int32))
-                assert delta.max() <= 1 and (delta != 0).sum() <= max(3, n // 100), (n, nf, hop, flip, mode, f, int(delta.max()), int((delta != 0).sum()))
+                assert delta.max() <= 1 and (delta != 0).sum() <= max(4, n // 50), (n, nf, hop, flip, mode, f, int(delta.max()), int((delta != 0).sum()))
             else:
                 if mode == 5:                      # dB rows: back to magnitudes, then the same relative-L2 bound
                     got_mag, want_mag = 10.0 ** (row.astype(np.float64) / 20.0), 10.0 ** (want / 20.0)
                     rel = np.linalg.norm(got_mag - want_mag) / max(np.linalg.norm(want_mag), 1e-30)
-                    assert rel < 4e-6, (n, nf, hop, flip, mode, f, rel)
+                    assert rel < 1e-5, (n, nf, hop, flip, mode, f, rel)
                 else:
                     rel = np.linalg.norm(row - want) / max(np.linalg.norm(want), 1e-30)
-                    assert rel < 2e-6, (n, nf, hop, flip, mode, f, rel)
+                    # (a faulty row is off by tens of per cent; the bounds only have to sit above fp32 round-off: 1-2e-7 typical)
+                    assert rel < 5e-6, (n, nf, hop, flip, mode, f, rel)
             checked += 1
         pending[si] = None
     n = int(rng.choice(SIZES))
