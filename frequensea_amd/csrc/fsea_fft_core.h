@@ -393,8 +393,8 @@ __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(flo
 // between identical launches in lanes 12-15 of a row, first register of the quad, beyond the first unit of the
 // first-placed workgroups (scripts/soak.py found it; profiles/r02_store_data_hazard.txt).  In isolation the hardware needs
 // two wait states (scripts/ubench/store_data_hazard.hip: none -> 23 % of the stores wrong, one -> 0.8 %, two -> none); in
-// these kernels two were not enough and three were (not isolated why; likeliest the co-resident wave's packed FMAs competing
-// for the register file).  Sixteen are spent here (five times what
+// these kernels two were not enough and three were (not isolated why; packed-FMA neighbours alone do not reproduce it in the
+// microbenchmark).  Sixteen are spent here (five times what
 // was ever seen to be needed; the wave only idles while its neighbour works), fenced so that the scheduler cannot move the
 // next writer in front of them.
 // FSEA_STORE_GUARD: 1 = that (default), 0 = nothing (the pre-fix code, for the regression evidence), 2 = two 8-byte

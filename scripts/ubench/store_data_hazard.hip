@@ -12,9 +12,17 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // the FFT kernels' form: buffer_store_dwordx4 with a VGPR offset (offen), an SGPR offset and nt
-template <int K>
+template <int K, bool HOGS = false>
 __global__ __launch_bounds__(256) void kb(uint4 *out, int iters, unsigned long long total_bytes) {
     const unsigned lane = threadIdx.x, wave_global = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (HOGS && (blockIdx.x & 1)) {
+        // the neighbours the FFT kernels have: wavefronts issuing packed FMAs with three 64-bit register operands back to back
+        for (int it = 0; it < iters * 24; ++it) {
+            asm volatile(".rept 16\n\tv_pk_fma_f32 v[30:31], v[32:33], v[34:35], v[36:37]\n\tv_pk_fma_f32 v[38:39], v[40:41], v[42:43], v[44:45]\n\t.endr"
+                         ::: "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45");
+        }
+        return;
+    }
     const unsigned long long base = (unsigned long long)out;
     const u32x4 rsrc = {(unsigned)base, (unsigned)(base >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
     (void)total_bytes;
@@ -55,10 +63,10 @@ __global__ __launch_bounds__(256) void k(uint4 *out, int iters) {
     }
 }
 
-template <int K, bool BUFFER>
+template <int K, bool BUFFER, bool HOGS = false>
 static void run(uint4 *d_out, std::vector<uint4> &h, int blocks, int iters) {
     hipMemset(d_out, 0, h.size() * sizeof(uint4));
-    if (BUFFER) hipLaunchKernelGGL(kb<K>, dim3(blocks), dim3(256), 0, 0, d_out, iters, (unsigned long long)(h.size() * sizeof(uint4)));
+    if (BUFFER) hipLaunchKernelGGL((kb<K, HOGS>), dim3(blocks), dim3(256), 0, 0, d_out, iters, (unsigned long long)(h.size() * sizeof(uint4)));
     else hipLaunchKernelGGL(k<K>, dim3(blocks), dim3(256), 0, 0, d_out, iters);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), d_out, h.size() * sizeof(uint4), hipMemcpyDeviceToHost);
@@ -67,11 +75,12 @@ static void run(uint4 *d_out, std::vector<uint4> &h, int blocks, int iters) {
     for (size_t i = 0; i < h.size(); ++i) {
         const unsigned lane = (unsigned)(i & 63), it = (unsigned)((i / 64) % iters);
         const unsigned want = 0x10000000u | (it << 8) | (((i / 64 / iters) % 4) * 64 + lane);
+        if (HOGS && ((i / 64 / iters / 4) & 1)) continue;            // a hog block: nothing stored
         if (h[i].x != want) { ++bad; ++by_quarter[(lane % 16) / 4]; }
-        if (h[i].y != want + 1 || h[i].z != want + 2 || h[i].w != want + 3) ++other;
+        if (!(HOGS && ((i / 64 / iters / 4) & 1)) && (h[i].y != want + 1 || h[i].z != want + 2 || h[i].w != want + 3)) ++other;
     }
     printf("%s K=%d wait states: %zu of %zu stores wrote something else in dword 0 (lanes 0-3 / 4-7 / 8-11 / 12-15 of a 16-lane row: %zu / %zu / %zu / %zu); other mismatches %zu\n",
-           BUFFER ? "buffer_store_dwordx4 offen+soffset nt, v_fma fillers:" : "global_store_dwordx4 nt, v_mov fillers:          ", K, bad, h.size(), by_quarter[0], by_quarter[1], by_quarter[2], by_quarter[3], other);
+           HOGS ? "buffer_store_dwordx4, packed-FMA neighbours on the SIMD:" : BUFFER ? "buffer_store_dwordx4 offen+soffset nt, v_fma fillers:" : "global_store_dwordx4 nt, v_mov fillers:          ", K, bad, h.size(), by_quarter[0], by_quarter[1], by_quarter[2], by_quarter[3], other);
 }
 
 int main() {
@@ -90,6 +99,10 @@ int main() {
         run<3, true>(d_out, h, blocks, iters);
         run<4, true>(d_out, h, blocks, iters);
         run<6, true>(d_out, h, blocks, iters);
+        run<1, true, true>(d_out, h, blocks, iters);
+        run<2, true, true>(d_out, h, blocks, iters);
+        run<3, true, true>(d_out, h, blocks, iters);
+        run<4, true, true>(d_out, h, blocks, iters);
     }
     hipFree(d_out);
     return 0;
