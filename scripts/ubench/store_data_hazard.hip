@@ -12,7 +12,7 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // the FFT kernels' form: buffer_store_dwordx4 with a VGPR offset (offen), an SGPR offset and nt
-template <int K, bool HOGS = false>
+template <int K, bool HOGS = false, bool SALU = false>
 __global__ __launch_bounds__(256) void kb(uint4 *out, int iters, unsigned long long total_bytes) {
     const unsigned lane = threadIdx.x, wave_global = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
     if (HOGS && (blockIdx.x & 1)) {
@@ -34,13 +34,13 @@ __global__ __launch_bounds__(256) void kb(uint4 *out, int iters, unsigned long l
             "v_mov_b32 v20, %[a]\n\tv_mov_b32 v21, %[b]\n\tv_mov_b32 v22, %[c]\n\tv_mov_b32 v23, %[d]\n\t"
             "s_nop 7\n\t"
             "buffer_store_dwordx4 v[20:23], %[voff], %[rsrc], %[soff] offen nt\n\t"
-            ".rept %c[k]\n\tv_fma_f32 v24, v25, v25, v26\n\t.endr\n\t"
+            ".if %c[salu]\n\t.rept %c[k]\n\ts_mov_b32 s40, s40\n\t.endr\n\t.else\n\t.rept %c[k]\n\tv_fma_f32 v24, v25, v25, v26\n\t.endr\n\t.endif\n\t"
             "v_fma_f32 v20, v25, v25, v26\n\t"
             "s_nop 7\n\t"
             :
             : [a] "v"(a), [b] "v"(b), [c] "v"(c), [d] "v"(d), [voff] "v"(voff), [rsrc] "s"(rsrc),
-              [soff] "s"(__builtin_amdgcn_readfirstlane(soff)), [k] "n"(K)
-            : "v20", "v21", "v22", "v23", "v24", "memory");
+              [soff] "s"(__builtin_amdgcn_readfirstlane(soff)), [k] "n"(K), [salu] "n"(SALU ? 1 : 0)
+            : "v20", "v21", "v22", "v23", "v24", "s40", "memory");
     }
 }
 
@@ -63,10 +63,10 @@ __global__ __launch_bounds__(256) void k(uint4 *out, int iters) {
     }
 }
 
-template <int K, bool BUFFER, bool HOGS = false>
+template <int K, bool BUFFER, bool HOGS = false, bool SALU = false>
 static void run(uint4 *d_out, std::vector<uint4> &h, int blocks, int iters) {
     hipMemset(d_out, 0, h.size() * sizeof(uint4));
-    if (BUFFER) hipLaunchKernelGGL((kb<K, HOGS>), dim3(blocks), dim3(256), 0, 0, d_out, iters, (unsigned long long)(h.size() * sizeof(uint4)));
+    if (BUFFER) hipLaunchKernelGGL((kb<K, HOGS, SALU>), dim3(blocks), dim3(256), 0, 0, d_out, iters, (unsigned long long)(h.size() * sizeof(uint4)));
     else hipLaunchKernelGGL(k<K>, dim3(blocks), dim3(256), 0, 0, d_out, iters);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), d_out, h.size() * sizeof(uint4), hipMemcpyDeviceToHost);
@@ -80,7 +80,7 @@ static void run(uint4 *d_out, std::vector<uint4> &h, int blocks, int iters) {
         if (!(HOGS && ((i / 64 / iters / 4) & 1)) && (h[i].y != want + 1 || h[i].z != want + 2 || h[i].w != want + 3)) ++other;
     }
     printf("%s K=%d wait states: %zu of %zu stores wrote something else in dword 0 (lanes 0-3 / 4-7 / 8-11 / 12-15 of a 16-lane row: %zu / %zu / %zu / %zu); other mismatches %zu\n",
-           HOGS ? "buffer_store_dwordx4, packed-FMA neighbours on the SIMD:" : BUFFER ? "buffer_store_dwordx4 offen+soffset nt, v_fma fillers:" : "global_store_dwordx4 nt, v_mov fillers:          ", K, bad, h.size(), by_quarter[0], by_quarter[1], by_quarter[2], by_quarter[3], other);
+           SALU ? "buffer_store_dwordx4, wait states made of SALU instructions:" : HOGS ? "buffer_store_dwordx4, packed-FMA neighbours on the SIMD:" : BUFFER ? "buffer_store_dwordx4 offen+soffset nt, v_fma fillers:" : "global_store_dwordx4 nt, v_mov fillers:          ", K, bad, h.size(), by_quarter[0], by_quarter[1], by_quarter[2], by_quarter[3], other);
 }
 
 int main() {
@@ -103,6 +103,12 @@ int main() {
         run<2, true, true>(d_out, h, blocks, iters);
         run<3, true, true>(d_out, h, blocks, iters);
         run<4, true, true>(d_out, h, blocks, iters);
+        run<1, true, false, true>(d_out, h, blocks, iters);
+        run<2, true, false, true>(d_out, h, blocks, iters);
+        run<3, true, false, true>(d_out, h, blocks, iters);
+        run<4, true, false, true>(d_out, h, blocks, iters);
+        run<6, true, false, true>(d_out, h, blocks, iters);
+        run<8, true, false, true>(d_out, h, blocks, iters);
     }
     hipFree(d_out);
     return 0;
