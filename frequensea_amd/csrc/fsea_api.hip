@@ -35,10 +35,12 @@ extern "C" int fsea_kernels_tune_abl(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_mid(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_px(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_big(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_w64(fsea::KernelEntry *out, int cap);
 #endif
 
 #define FSEA_STATIC_UNITS_PER_WG 16u  // measured crossover: profiles/r02_static_vs_ticket_distribution.txt
 #define FSEA_CTR_SLOTS 64u          // ticket-counter slots = streams one plan may be launched on concurrently
+#define FSEA_HOST_CHUNKS_MAX 16      // chunks of one host-buffer call (fsea_exec_*_host) in flight
 #define FSEA_CTR_WORDS (9u * 32u + 2048u)  // 8 ticket pools + the finished-workgroups word, one 128-byte line each; one progress word per workgroup (tuning option)
 
 namespace {
@@ -73,6 +75,7 @@ const std::vector<fsea::KernelEntry> &registry() {
 #ifdef FSEA_TUNE
                                                     fsea_kernels_tune_8192a, fsea_kernels_tune_8192b,
                                                     fsea_kernels_tune_abl, fsea_kernels_tune_px, fsea_kernels_tune_mid, fsea_kernels_tune_big,
+                                                    fsea_kernels_tune_w64,
 #endif
         };
         for (auto fn : lists) {
@@ -267,6 +270,10 @@ struct fsea_plan {
     void *h_out = nullptr;
     size_t h_in_bytes = 0, h_out_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the pipelined host-buffer path (exec_host_pipelined): copy-in and copy-out streams beside `stream`, and one
+    // "chunk arrived" / "chunk transformed" event pair per chunk in flight
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_in[FSEA_HOST_CHUNKS_MAX] = {}, ev_done[FSEA_HOST_CHUNKS_MAX] = {};
     std::string kernel_name;
 };
 
@@ -466,6 +473,12 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     if (he == hipSuccess) he = hipDeviceSynchronize();
     if (he == hipSuccess) he = hipEventCreate(&p->ev0);
     if (he == hipSuccess) he = hipEventCreate(&p->ev1);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking);
+    for (unsigned c = 0; c < FSEA_HOST_CHUNKS_MAX && he == hipSuccess; ++c) {
+        he = hipEventCreateWithFlags(&p->ev_in[c], hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&p->ev_done[c], hipEventDisableTiming);
+    }
     for (int k = 0; k < fsea::K_COUNT && he == hipSuccess; ++k) {
         if (e->fn[k]) he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p->occ[k], e->fn[k], e->wg, 0);
     }
@@ -512,6 +525,12 @@ int fsea_plan_destroy(fsea_plan *p) {
     if (p->d_ctr) (void)hipFree(p->d_ctr);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (unsigned c = 0; c < FSEA_HOST_CHUNKS_MAX; ++c) {
+        if (p->ev_in[c]) (void)hipEventDestroy(p->ev_in[c]);
+        if (p->ev_done[c]) (void)hipEventDestroy(p->ev_done[c]);
+    }
+    if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
+    if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
     return FSEA_OK;
@@ -584,6 +603,96 @@ int fsea_exec_u8_tiled_device(fsea_plan *p, const void *d_iq, size_t n_frames, i
 
 namespace {
 
+// Pins the caller's buffer in place for the duration of one call, if the runtime lets us: copies from / to pinned pages
+// are truly asynchronous (the two directions overlap: 2.56 instead of 3.57 ms for 64 MiB in + 128 MiB out on this box,
+// profiles/r03_host_path.txt), pageable ones are staged by the runtime and return when done.  Memory that is pinned
+// already (hipHostMalloc, fsea_host_alloc, registered by the caller) is left alone.
+struct PinnedInPlace {
+    void *ptr = nullptr;
+    PinnedInPlace(const void *p, size_t bytes) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return;  // pinned or device
+        (void)hipGetLastError();
+        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void *>(p);
+        else (void)hipGetLastError();  // read-only mapping, foreign registration, ...: pageable copies still work
+    }
+    ~PinnedInPlace() {
+        if (ptr) (void)hipHostUnregister(ptr);
+    }
+    PinnedInPlace(const PinnedInPlace &) = delete;
+    PinnedInPlace &operator=(const PinnedInPlace &) = delete;
+};
+
+// Host-buffer execution, pipelined: the batch is cut into chunks of whole frames; chunk c's bytes travel on the copy-in
+// stream while chunk c-1 is transformed on the plan's stream and chunk c-2's rows travel back on the copy-out stream
+// (events order the three).  The streaming shape of the reference's tools (c/fft-batch.c:54-102: one transfer in, one
+// row out) at the granularity a PCIe link wants.  bytes_per_sample: 2 (u8 IQ) or 16 (f64 IQ, narrowed on the device).
+int exec_host_pipelined(fsea_plan *p, int in_kind, const void *in, size_t bytes_per_sample, size_t n_frames, int flip,
+                        void *out, double rot_delta, double rot_phase0) {
+    const size_t n = (size_t)p->n, hop = (size_t)p->hop;
+    const size_t row_bytes = fsea_plan_row_bytes(p);
+    const size_t n_samples = (n_frames - 1) * hop + n;
+    const size_t in_bytes = n_samples * bytes_per_sample, out_bytes = n_frames * row_bytes;
+    const bool f64 = bytes_per_sample == 16;
+    int rc = ensure(f64 ? &p->d_aux : &p->d_in, f64 ? &p->d_aux_bytes : &p->d_in_bytes, in_bytes);
+    if (rc) return rc;
+    if (f64) {
+        rc = ensure(&p->d_in, &p->d_in_bytes, n_samples * 2 * sizeof(float));
+        if (rc) return rc;
+    }
+    rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
+    if (rc) return rc;
+    // chunks of about 24 MiB (in + out): long enough for the link's full rate, short enough that the first copy-in and
+    // the last copy-out (the two pieces nothing overlaps) are a small part of the call
+    size_t chunks = (in_bytes + out_bytes) / ((size_t)24 << 20);
+    if (chunks < 1) chunks = 1;
+    if (chunks > FSEA_HOST_CHUNKS_MAX) chunks = FSEA_HOST_CHUNKS_MAX;
+    size_t per = (n_frames + chunks - 1) / chunks;
+    const size_t fpw = (size_t)p->entry->fpw;
+    per = (per + fpw - 1) / fpw * fpw;  // whole units, so that a chunk boundary never splits a workgroup's frames
+    chunks = (n_frames + per - 1) / per;
+    PinnedInPlace pin_in(in, in_bytes), pin_out(out, out_bytes);
+    auto run = [&]() -> int {
+        const char *src = static_cast<const char *>(in);
+        char *d_src = static_cast<char *>(f64 ? p->d_aux : p->d_in);
+        size_t copied = 0;  // input bytes already on their way
+        for (size_t c = 0; c < chunks; ++c) {
+            const size_t f0 = c * per, f1 = (f0 + per < n_frames) ? f0 + per : n_frames;
+            const size_t need = ((f1 - 1) * hop + n) * bytes_per_sample;  // everything chunk c reads (with its overlap into the next)
+            if (need > copied) {
+                FSEA_HIP(hipMemcpyAsync(d_src + copied, src + copied, need - copied, hipMemcpyHostToDevice, p->s_h2d));
+                copied = need;
+            }
+            FSEA_HIP(hipEventRecord(p->ev_in[c], p->s_h2d));
+            FSEA_HIP(hipStreamWaitEvent(p->stream, p->ev_in[c], 0));
+            const char *d_frames = static_cast<const char *>(p->d_in) + f0 * hop * (f64 ? 2 * sizeof(float) : 2);
+            if (f64) {
+                const size_t v0 = f0 * hop * 2, v1 = ((f1 - 1) * hop + n) * 2;  // doubles of this chunk
+                unsigned blocks = (unsigned)((v1 - v0 + 255) / 256);
+                if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(fsea_f64_to_f32_kernel, dim3(blocks), dim3(256), 0, p->stream,
+                                   static_cast<const double *>(p->d_aux) + v0, static_cast<float *>(p->d_in) + v0, v1 - v0);
+            }
+            const int lrc = launch(p, in_kind, d_frames, f1 - f0, flip, p->mode, static_cast<char *>(p->d_out) + f0 * row_bytes,
+                                   p->stream, rot_delta, rot_phase0 + rot_delta * (double)(f0 * hop));
+            if (lrc) return lrc;
+            FSEA_HIP(hipEventRecord(p->ev_done[c], p->stream));
+            FSEA_HIP(hipStreamWaitEvent(p->s_d2h, p->ev_done[c], 0));
+            FSEA_HIP(hipMemcpyAsync(static_cast<char *>(out) + f0 * row_bytes, static_cast<char *>(p->d_out) + f0 * row_bytes,
+                                    (f1 - f0) * row_bytes, hipMemcpyDeviceToHost, p->s_d2h));
+        }
+        FSEA_HIP(hipStreamSynchronize(p->s_d2h));
+        return FSEA_OK;
+    };
+    rc = run();
+    if (rc) {  // nothing of this call may still be using the caller's pages when they are unpinned
+        (void)hipStreamSynchronize(p->s_h2d);
+        (void)hipStreamSynchronize(p->stream);
+        (void)hipStreamSynchronize(p->s_d2h);
+    }
+    return rc;
+}
+
 // Common body of the u8 host entry points.
 int exec_u8_host(fsea_plan *p, int in_kind, const uint8_t *iq, size_t n_frames, int flip, void *out, double rot_delta,
                  double rot_phase0) {
@@ -609,16 +718,7 @@ int exec_u8_host(fsea_plan *p, int in_kind, const uint8_t *iq, size_t n_frames, 
         std::memcpy(out, p->h_out, out_bytes);
         return FSEA_OK;
     }
-    int rc = ensure(&p->d_in, &p->d_in_bytes, in_bytes);
-    if (rc) return rc;
-    rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
-    if (rc) return rc;
-    FSEA_HIP(hipMemcpyAsync(p->d_in, iq, in_bytes, hipMemcpyHostToDevice, p->stream));
-    rc = launch(p, in_kind, p->d_in, n_frames, flip, p->mode, p->d_out, p->stream, rot_delta, rot_phase0);
-    if (rc) return rc;
-    FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-    FSEA_HIP(hipStreamSynchronize(p->stream));
-    return FSEA_OK;
+    return exec_host_pipelined(p, in_kind, iq, 2, n_frames, flip, out, rot_delta, rot_phase0);
 }
 
 }  // namespace
@@ -673,23 +773,7 @@ int fsea_exec_f64_host(fsea_plan *p, const double *iq, size_t n_frames, void *ou
         std::memcpy(out, p->h_out, out_bytes);
         return FSEA_OK;
     }
-    int rc = ensure(&p->d_aux, &p->d_aux_bytes, n_samples * 2 * sizeof(double));
-    if (rc) return rc;
-    rc = ensure(&p->d_in, &p->d_in_bytes, n_samples * 2 * sizeof(float));
-    if (rc) return rc;
-    rc = ensure(&p->d_out, &p->d_out_bytes, out_bytes);
-    if (rc) return rc;
-    FSEA_HIP(hipMemcpyAsync(p->d_aux, iq, n_samples * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    const size_t n_vals = n_samples * 2;
-    unsigned blocks = (unsigned)((n_vals + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fsea_f64_to_f32_kernel, dim3(blocks), dim3(256), 0, p->stream,
-                       static_cast<const double *>(p->d_aux), static_cast<float *>(p->d_in), n_vals);
-    rc = launch(p, fsea::IN_F32, p->d_in, n_frames, 0, p->mode, p->d_out, p->stream);
-    if (rc) return rc;
-    FSEA_HIP(hipMemcpyAsync(out, p->d_out, out_bytes, hipMemcpyDeviceToHost, p->stream));
-    FSEA_HIP(hipStreamSynchronize(p->stream));
-    return FSEA_OK;
+    return exec_host_pipelined(p, fsea::IN_F32, iq, 16, n_frames, 0, out, 0.0, 0.0);
 }
 
 // ---- device-resident history ring (nrf_fft's history behind NRF_FFT_HISTORY=device) ----
@@ -909,6 +993,19 @@ int fsea_device_free(int device, void *d_ptr) {
     if (!d_ptr) return FSEA_OK;
     FSEA_ON_DEVICE(device);
     FSEA_HIP(hipFree(d_ptr));
+    return FSEA_OK;
+}
+
+int fsea_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr) return fail(FSEA_EINVAL, "NULL out-pointer");
+    *ptr = nullptr;
+    FSEA_HIP(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocPortable));
+    return FSEA_OK;
+}
+
+int fsea_host_free(void *ptr) {
+    if (!ptr) return FSEA_OK;
+    FSEA_HIP(hipHostFree(ptr));
     return FSEA_OK;
 }
 

@@ -136,3 +136,21 @@
 #define FSEA_CFG_4096_X0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 0
 #define FSEA_CFG_2048_X0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 0
 #define FSEA_CFG_1024_X0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 0
+// 4096 points as ONE wavefront per frame, 64 lanes x 64 points, no s_barrier (round 3):
+// "w64": 64 x 64, one exchange (FftKernel::run_w64; OPT 1048576), last-pass twiddles deferred and register-resident;
+// "s2": 16 x 16 x 16 in the V1 schedule, two exchanges, dwordx2 loads and four adjacent bins per lane in the last pass
+#define FSEA_CFG_4096_W64 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, 1085442
+#define FSEA_CFG_4096_S2 4096, 64, 1, 1, 3, 16, 16, 16, 1, true, true, 0, 37022
+#define FSEA_CFG_4096_W64B 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, 5279746   /* + biased rounding instead of v_trunc */
+// pixel epilogue with v_cvt_pk_u8_f32 (OPT 2097152: v_trunc + convert-and-pack; + 4194304: biased rounding, no v_trunc)
+// "pk": with the v_trunc (exact truncation); "px0": the round-2 form (cast, clamp, shift/or); the product has both bits
+#define FSEA_CFG_4096_PK 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 2134206
+#define FSEA_CFG_4096_PX0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 37054
+#define FSEA_CFG_8192_PK 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 2134174
+#define FSEA_CFG_8192_PX0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 37022
+#define FSEA_CFG_256_PK 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 2101248
+#define FSEA_CFG_256_PX0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 4096
+#define FSEA_CFG_1024_PX0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 4106
+// 256 points with 64 points per lane (4 lanes per frame, 16 x 16 with four columns: dwordx2 loads, four adjacent bins per
+// lane in the last pass), one wave per workgroup, one wave per SIMD
+#define FSEA_CFG_256_P64 256, 4, 16, 1, 2, 16, 16, 1, 1, true, true, 0, 4096

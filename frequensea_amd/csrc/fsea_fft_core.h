@@ -587,6 +587,8 @@ struct FftKernel {
     static constexpr bool DEFER = (Cfg::OPT & 128) != 0 && NP == 3;
     static constexpr bool TK_LATE = (Cfg::OPT & 512) != 0 && NP >= 3 && !ONE_WAVE && (Cfg::ABL & 2) == 0;
     static constexpr bool MI = (Cfg::OPT & 256) == 0;  // OPT 256: the +-i butterflies as packed FMAs by (+-1, -+1) (round-1 form)
+    static constexpr bool PX_PACK = (Cfg::OPT & 2097152) != 0;   // pixel epilogue: v_trunc + v_cvt_pk_u8_f32
+    static constexpr bool PX_BIAS = (Cfg::OPT & 4194304) != 0;   // ... without the v_trunc (biased round-to-nearest)
     static constexpr bool LANE_ROT = (Cfg::OPT & 16) != 0;       // middle passes
     static constexpr bool LANE_ROT_LAST = (Cfg::OPT & 32) != 0;  // the last pass as well
     // Which frame-lane a physical lane works as in pass I >= 1.  Any bijection is valid: passes meet
@@ -867,6 +869,7 @@ struct FftKernel {
             for (int r = 0; r < RL; ++r) {
                 const uint32_t soff = (uint32_t)(r * NsL);
                 uint8_t px[CL];
+                [[maybe_unused]] uint32_t pxw[(CL + 3) / 4] = {};
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
                     const cf z = v[r * CL + c];
@@ -876,11 +879,28 @@ struct FftKernel {
                     // half an ulp whenever the pixel is not clamped to 0 anyway (p > 1e-13), and for
                     // smaller p -- down to log2(0) = -inf, which the conversion saturates -- the pixel
                     // is 0 either way.  Left out: same pixels, one VALU op less per bin.
-                    float d = kdb * __builtin_amdgcn_logf(p);
-                    if constexpr (Cfg::ABL & 128) d = kdb * p;  // ABL 128 (measurement only): no logarithm
-                    int q = (int)d;  // truncation toward zero, as the C cast in the reference
-                    q = q < 0 ? 0 : (q > 255 ? 255 : q);
-                    px[c] = (uint8_t)q;
+                    if constexpr (PX_PACK) {
+                        // OPT 2097152: truncation (v_trunc_f32), then v_cvt_pk_u8_f32, which saturates to [0, 255] and
+                        // drops the byte into place: 2 ops where the cast + clamp + shift/or packing took 2 + ~0.75.
+                        // OPT 4194304 (with it): no v_trunc; the conversion rounds to nearest even, so d is lowered by
+                        // 0.5 - 2^-25 in the FMA that forms it: floor(d) except for d within ~8e-6 above an odd integer
+                        // (one pixel in ~2.5e5 one grey level low; the f32 logarithm itself moves more than that).
+                        float d;
+                        if constexpr (PX_BIAS) d = __builtin_fmaf(kdb, __builtin_amdgcn_logf(p), -0.49999997f);
+                        else d = trunc_f32(kdb * __builtin_amdgcn_logf(p));
+                        if constexpr (Cfg::ABL & 128) d = kdb * p;
+                        pxw[c / 4] = cvt_pk_u8(d, (uint32_t)(c & 3), pxw[c / 4]);
+                    } else {
+                        float d = kdb * __builtin_amdgcn_logf(p);
+                        if constexpr (Cfg::ABL & 128) d = kdb * p;  // ABL 128 (measurement only): no logarithm
+                        int q = (int)d;  // truncation toward zero, as the C cast in the reference
+                        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                        px[c] = (uint8_t)q;
+                    }
+                }
+                if constexpr (PX_PACK) {
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) px[c] = (uint8_t)(pxw[c / 4] >> (8 * (c & 3)));  // (only the patched lanes' byte stores read these)
                 }
                 if constexpr (Cfg::ABL & 1) {
                     if (px[0] == 255 && px[CL - 1] == 254 && v[0][0] == -1.0f) bst<CL>(out, voff, soff, px);  // (practically) never
@@ -894,6 +914,13 @@ struct FftKernel {
                 } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + c, soff, px + c);
+                } else if constexpr (PX_PACK) {
+                    if constexpr (CL == 1) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)pxw[0], out, voff, soff, st_aux<1>());
+                    else if constexpr (CL == 2) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pxw[0], out, voff, soff, st_aux<1>());
+                    else {
+#pragma unroll
+                        for (int c = 0; c < CL; c += 4) __builtin_amdgcn_raw_buffer_store_b32(pxw[c / 4], out, voff + c, soff, st_aux<1>());
+                    }
                 } else {
                     bst<CL, st_aux<1>()>(out, voff, soff, px);
                 }
@@ -981,9 +1008,160 @@ struct FftKernel {
 
     static constexpr bool V2 = (Cfg::OPT & 64) != 0;
 
+    static constexpr bool W64 = (Cfg::OPT & 1048576) != 0;
+
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
-        if constexpr (V2) run_v2(a, lds_all);
+        if constexpr (W64) run_w64(a, lds_all);
+        else if constexpr (V2) run_v2(a, lds_all);
         else run_v1(a, lds_all);
+    }
+
+    // -----------------------------------------------------------------------------------------
+    // W64 schedule (OPT 1048576): N = 64 x 64, one wavefront per frame, 64 points per lane, ONE exchange
+    // through LDS and no s_barrier at all.
+    //
+    // Sample n = 64 n1 + n2, bin k = k1 + 64 k2.  Pass 0: lane n2 transforms x[64 n1 + n2] over n1 (64 points, constant
+    // twiddles) -> y[k1]; exchange: element (k1, n2) goes from lane n2 to lane k1; pass 1: lane k1 transforms over n2 with
+    // the twiddles W_N^{n2 k1} deferred into the butterflies (dft_regs_def; 32 register pairs per lane, resident) -> k2.
+    //   * (-1)^n = (-1)^{n2} is a shift of the spectrum by N/2 bins = of k2 by 32: nothing is negated, row r of the
+    //     last pass is bin k1 + 64 (r ^ 32) -- register renaming.
+    //   * Loads.  A lane holding one sample per row would load 2 bytes at a time.  Instead lane L loads the dword
+    //     sigma(L) + 64 j (j < 32): 256 contiguous bytes per wave instruction, two adjacent samples (n2 = 2d, 2d + 1) of
+    //     row n1 = 2j (+1 in lanes 32-63: sigma(L + 32) = sigma(L) + 32).  Lanes L and L + 32 therefore hold the same
+    //     two n2 with complementary n1, and ONE v_permlane32_swap_b32 per pair of rows hands each the other's half:
+    //     A = perm(keep / send), B = perm(send / keep), swap(A, B) -> A = rows (2j, 2j'), B = rows (2j + 1, 2j' + 1)
+    //     of the lane's own n2, the same registers in every lane.  Three VALU ops per four samples.
+    //   * Which n2 a lane ends up with is free (passes meet in LDS at logical addresses); sigma and the kept half are
+    //     chosen so that the 16 lanes of every ds_write_b64 lane group hold n2 that differ mod 16 (conflict-free):
+    //     n2(L) = 2 pi(L & 31) + ((L >> 5) ^ (L & 1)), pi(t) = (t & 16) + ((t & 15) >> 1) + 8 (t & 1).
+    //   * LDS: element (k1, n2) at k1 * 66 + n2 (complex units; 16 bytes of pad per row): 64 ds_write_b64 whose lanes
+    //     cover one 512-byte row each, 32 ds_read_b128 of the lane's own row (row pitch 33 x 16 bytes: conflict-free).
+    //   * Pixel rows (u8 modes): a lane's 64 pixels are bins k1 + 64 r, one byte each.  Four rows are packed into a dword
+    //     by v_cvt_pk_u8_f32 (conversion and packing in one op), transposed 4 x 4 inside each quad of lanes (two
+    //     v_mov_b32_dpp quad_perm + two v_perm_b32) and stored as dwords: lane 4m + i writes bins 4m .. 4m+3 of row
+    //     4q + i, the wave 256 contiguous bytes per instruction, 16 stores per frame.
+    // -----------------------------------------------------------------------------------------
+    static __device__ __forceinline__ void run_w64(const FftArgs &a, cf *lds) {
+        static_assert(!W64 || (N == 4096 && T == 64 && FPW == 1 && NP == 2 && R0 == 64 && RL == 64), "W64 is the 64 x 64 layout");
+        static_assert(!W64 || (IN == IN_U8 && !ROT), "W64 serves the u8 kernels");
+        static_assert(!W64 || (!Cfg::TWL && !Cfg::TWR), "W64 keeps its (deferred) twiddles in registers: no table block in LDS");
+        constexpr int ROW = 66;  // LDS row pitch in complex units
+        const int L = threadIdx.x;
+        const unsigned b = blockIdx.x;
+        const size_t n_units = a.n_frames;
+        const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
+        const uint32_t xormask = (MODE_T >= 0) ? 0u : a.xormask;
+        const uint32_t esz = elem_bytes(mode);
+        const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
+        const bool tiled = a.tile_rows != 0;
+        const size_t total_out = (size_t)esz * (tiled ? a.out_span : a.n_frames * (size_t)N);
+        auto row_elem = [&](size_t f) -> size_t {
+            if (!tiled) return f * (size_t)N;
+            const uint32_t k = (uint32_t)f / a.tile_rows, y = (uint32_t)f - k * a.tile_rows;
+            return (size_t)y * a.pitch_row + (size_t)k * a.pitch_tile;
+        };
+        // pass-0 identity of this lane
+        const int t5 = L & 31, odd = L & 1, hi = L >> 5;
+        const int pi = (t5 & 16) + ((t5 & 15) >> 1) + 8 * odd;
+        const int n2 = 2 * pi + (hi ^ odd);
+        const uint32_t in_voff = 4u * (uint32_t)(pi + 32 * hi);
+        const uint32_t sel_a = odd ? 0x07060302u : 0x05040100u;  // the half (sample) that ends up in A: c = L & 1
+        const uint32_t sel_b = odd ? 0x05040100u : 0x07060302u;
+        // this lane's deferred twiddles of the last pass: row k1 = L of the [64][32] table (build_deferred_table)
+        cf twd[RL / 2];
+        ld_c<RL / 2>(a.tw_def + (size_t)L * (RL / 2), twd);
+
+        auto load_frame = [&](size_t u, uint32_t *raw) {
+            const rsrc_t rs = buffer_window(a.in, (size_t)IN_BPS * u * a.hop, u < n_units ? total_in : 0);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_voff, (uint32_t)(256 * j), LD_AUX);
+        };
+        size_t u = b;
+        uint32_t raw[32];
+        load_frame(u, raw);
+        // the grid size lives in a VGPR: with the 64-point DFT's constants the SGPR file is full, and a gridDim.x re-read
+        // from the dispatch packet (s_load_dword) inside the loop is waited for with lgkmcnt(0) -- together with every
+        // LDS write in flight
+        unsigned grid_v = gridDim.x;
+#if defined(__AMDGCN__)
+        asm volatile("" : "+v"(grid_v));
+#endif
+        cf *const wr = lds + n2;               // + ROW k1
+        const cf *const rd = lds + ROW * L;    // + n2
+
+        while (u < n_units) {
+            cf v[64];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t wa = byte_perm(raw[j + 16], raw[j], sel_a);
+                uint32_t wb = byte_perm(raw[j + 16], raw[j], sel_b);
+                lane_swap32(wa, wb);
+                wa ^= xormask;
+                wb ^= xormask;
+                v[2 * j] = cf{s8f(wa, 0), s8f(wa, 1)};
+                v[2 * j + 32] = cf{s8f(wa, 2), s8f(wa, 3)};
+                v[2 * j + 1] = cf{s8f(wb, 0), s8f(wb, 1)};
+                v[2 * j + 33] = cf{s8f(wb, 2), s8f(wb, 3)};
+            }
+            dft_regs<64, 1, (Cfg::ABL & 4) != 0, MI>(v);
+            frame_sync();  // the previous frame's reads precede these writes
+            if constexpr ((Cfg::ABL & 2) == 0) {
+#pragma unroll
+                for (int k1 = 0; k1 < 64; ++k1) wr[ROW * k1] = v[k1];
+            }
+            frame_sync();
+            const size_t un = u + __builtin_amdgcn_readfirstlane(grid_v);
+            if constexpr ((Cfg::ABL & 64) == 0) load_frame(un, raw);
+            if constexpr ((Cfg::ABL & 2) == 0) {
+                // the first butterflies of pass 1 pair elements j and j + 32: fetched in that order
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    ld_c<2>(rd + 2 * q, v + 2 * q);
+                    ld_c<2>(rd + 2 * q + 32, v + 2 * q + 32);
+                }
+            }
+            after_reads();
+            if constexpr ((Cfg::ABL & 4) == 0) dft_regs_def<64, 1, 1>(v, twd);
+            cf w[64];  // centred order: row r = bin L + 64 r
+#pragma unroll
+            for (int r = 0; r < 64; ++r) w[r] = v[r ^ 32];
+            const rsrc_t out = buffer_window(a.out, (size_t)esz * row_elem(u), total_out);
+            if (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) pixels_w64(mode, out, w, L);
+            else epilogue(mode, out, (uint32_t)L, w, L);
+            u = un;
+        }
+    }
+
+    static __device__ __forceinline__ void pixels_w64(int mode, rsrc_t out, cf *w, int L) {
+        const bool patched = (mode == MODE_DB5_U8_DCFIX);
+        if (!patched && L == 0) w[32] += cf{128.0f * (float)N, 128.0f * (float)N};  // DC of the offset-binary samples (see epilogue)
+        const float kdb = (mode == MODE_DB10_U8 ? 100.0f : 50.0f) * 0.30102999566398120f;
+        const float koff = -16.0f * kdb;  // log2 of the 1/256^2 the integer-unit power still carries
+        const uint32_t sel1 = (L & 1) ? 0x03070105u : 0x06020400u;
+        const uint32_t sel2 = (L & 2) ? 0x03020706u : 0x05040100u;
+        const uint32_t voff = (uint32_t)((L & 3) * 64 + (L & ~3));
+        uint32_t left = 0;  // DB5: the pixel of bin N/2 - 1 (row 31, lane 63), copied over bin N/2 (row 32, lane 0)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            uint32_t px = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const cf z = w[4 * q + i];
+                const float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
+                float d = __builtin_fmaf(kdb, __builtin_amdgcn_logf(p), PX_BIAS ? koff - 0.49999997f : koff);
+                if constexpr (Cfg::ABL & 128) d = kdb * p;
+                px = cvt_pk_u8(PX_BIAS ? d : trunc_f32(d), (uint32_t)i, px);  // truncation toward zero, then saturation: the reference's cast + clamp
+            }
+            const uint32_t u1 = byte_perm(quad_xor1(px), px, sel1);
+            uint32_t rows = byte_perm(quad_xor2(u1), u1, sel2);  // lane 4m + i: bins 4m .. 4m + 3 of row 4q + i
+            if (q == 7) left = read_lane(rows, 63) >> 24;
+            if (q == 8 && patched && L == 0) rows = (rows & 0xffffff00u) | left;
+            if constexpr (Cfg::ABL & 1) {
+                if (rows == 0x01020304u && w[0][0] == -1.0f) __builtin_amdgcn_raw_buffer_store_b32(rows, out, voff, (uint32_t)(256 * q), ST_AUX);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(rows, out, voff, (uint32_t)(256 * q), ST_AUX);
+            }
+        }
     }
 
     // -----------------------------------------------------------------------------------------

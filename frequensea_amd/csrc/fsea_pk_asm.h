@@ -10,6 +10,8 @@
 // RAW dependencies are interlocked in hardware, no wait states are needed.
 #pragma once
 
+#include <stdint.h>
+
 namespace fsea {
 
 typedef float cf __attribute__((vector_size(8)));    // (re, im) in an aligned VGPR pair
@@ -60,6 +62,33 @@ __device__ __forceinline__ cf pk_cmul_add_mi(cf a, cf w, cf c) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "+v"(t) : "v"(a), "v"(w));
     return t;
 }
+
+
+// ---- cross-lane and byte primitives of the single-wave 64 x 64 schedule (FftKernel::run_w64) ----
+// v_permlane32_swap_b32: lanes 32-63 of `a` trade places with lanes 0-31 of `b` (a half exchange; the other two
+// halves stay).  The builtin lets hipcc place the wait states its operands need behind a VALU write.
+__device__ __forceinline__ void lane_swap32(uint32_t &a, uint32_t &b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// the value of lane ^ 1 / lane ^ 2 inside each quad (v_mov_b32_dpp quad_perm:[1,0,3,2] / [2,3,0,1])
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+}
+// v_perm_b32: result byte i = byte sel[8i+7:8i] of the eight bytes {hi, lo} (0-3 = lo, 4-7 = hi)
+__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+// v_cvt_pk_u8_f32: f converted to u8 (saturating; the argument is already integral) into byte `pos` of `old`
+__device__ __forceinline__ uint32_t cvt_pk_u8(float f, uint32_t pos, uint32_t old) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(f, pos, old);
+}
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ float trunc_f32(float x) { return __builtin_truncf(x); }
 
 // Diagnostics only (FSEA_TRACE): where a workgroup runs.
 __device__ __forceinline__ unsigned read_hw_id() {

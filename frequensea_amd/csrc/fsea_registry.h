@@ -96,6 +96,33 @@ struct KernelEntry {
             &NAME##_launch};                                                                          \
     }
 
+// The u8 kernels only (MAG, DB5, DB10 with the mode fixed, and the run-time-mode kernel): configurations that have no
+// f32-input or frequency-shifted form (the single-wave 64 x 64 schedule).
+#define FSEA_DEFINE_KERNEL_U8(NAME, VARIANT, ...)                                                     \
+    using NAME##_cfg = fsea::FftCfg<__VA_ARGS__>;                                                     \
+    FSEA_KERNEL_FN_(NAME, _u8_mag, fsea::IN_U8, fsea::MODE_MAG)                                       \
+    FSEA_KERNEL_FN_(NAME, _u8_db5, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX)                              \
+    FSEA_KERNEL_FN_(NAME, _u8_db10, fsea::IN_U8, fsea::MODE_DB10_U8)                                  \
+    FSEA_KERNEL_FN_(NAME, _u8, fsea::IN_U8)                                                           \
+    static void NAME##_launch(int kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {       \
+        const dim3 g(grid), b(NAME##_cfg::WG);                                                        \
+        switch (kind) {                                                                               \
+        case fsea::K_U8_MAG: hipLaunchKernelGGL(NAME##_u8_mag, g, b, 0, s, a); break;                 \
+        case fsea::K_U8_DB5: hipLaunchKernelGGL(NAME##_u8_db5, g, b, 0, s, a); break;                 \
+        case fsea::K_U8_DB10: hipLaunchKernelGGL(NAME##_u8_db10, g, b, 0, s, a); break;               \
+        default: hipLaunchKernelGGL(NAME##_u8, g, b, 0, s, a); break;                                 \
+        }                                                                                             \
+    }                                                                                                 \
+    static fsea::KernelEntry NAME##_entry() {                                                         \
+        return fsea::KernelEntry{                                                                     \
+            FSEA_KERNEL_ENTRY_HEAD_(NAME, VARIANT),                                                   \
+            {reinterpret_cast<const void *>(&NAME##_u8_mag), reinterpret_cast<const void *>(&NAME##_u8_db5), \
+             reinterpret_cast<const void *>(&NAME##_u8_db10), reinterpret_cast<const void *>(&NAME##_u8),    \
+             nullptr, nullptr},                                                                       \
+            {#NAME "_u8_mag", #NAME "_u8_db5", #NAME "_u8_db10", #NAME "_u8", "", ""},                \
+            &NAME##_launch};                                                                          \
+    }
+
 #define FSEA_REGISTER_BEGIN(TAG)                                                                      \
     extern "C" int fsea_kernels_##TAG(fsea::KernelEntry *out, int cap) {                              \
         int n = 0;

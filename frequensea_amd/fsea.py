@@ -26,7 +26,7 @@ EXPORTS = [
     "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device", "fsea_exec_u8_tiled_device", "fsea_plan_set_unit_distribution",
     "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_exec_u8_shifted_device", "fsea_exec_u8_shifted_host", "fsea_mean_magnitude_u8_device",
     "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
-    "fsea_copy_to_host", "fsea_stream_synchronize",
+    "fsea_copy_to_host", "fsea_stream_synchronize", "fsea_host_alloc", "fsea_host_free",
     "fsea_plan_kernel_name", "fsea_last_error_string",
     "fsea_history_create", "fsea_history_destroy", "fsea_history_push_u8_host", "fsea_history_push_f64_host",
     "fsea_history_shift", "fsea_history_get_f64",
@@ -120,6 +120,8 @@ def hip_lib():
         L.fsea_copy_to_device.argtypes = [ci, vp, vp, sz]
         L.fsea_copy_to_host.argtypes = [ci, vp, vp, sz]
         L.fsea_stream_synchronize.argtypes = [vp, vp]
+        L.fsea_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
+        L.fsea_host_free.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -235,6 +237,13 @@ class Plan:
         _check(self._L.fsea_exec_u8_host(self._p, iq.ctypes.data, n_frames, int(bool(flip)), out.ctypes.data))
         return out
 
+    def exec_host_into(self, iq_u8, n_frames, out, flip=True):
+        """fsea_exec_u8_host into a caller-owned array (any host memory: pageable numpy, or pinned_array())."""
+        if iq_u8.nbytes < self.in_bytes(n_frames) or out.nbytes < n_frames * self.row_bytes:
+            raise ValueError("buffers too short for %d frames" % n_frames)
+        _check(self._L.fsea_exec_u8_host(self._p, iq_u8.ctypes.data, n_frames, int(bool(flip)), out.ctypes.data))
+        return out
+
     def exec_shifted_device(self, d_iq_ptr, n_frames, d_out_ptr, cycles_per_sample, phase0_cycles=0.0, flip=True,
                             stream=0):
         """fsea_exec_u8_shifted_device: the frequency shifter fused into the FFT's load."""
@@ -263,6 +272,23 @@ class Plan:
         _check(self._L.fsea_mean_magnitude_u8_device(self._p, d_iq_ptr, n_frames, int(bool(flip)),
                                                      ctypes.byref(m), stream or None))
         return m.value
+
+
+class PinnedArray:
+    """A numpy view of fsea_host_alloc'ed (page-locked) memory; .array is valid until close()."""
+
+    def __init__(self, shape, dtype):
+        self._ptr = ctypes.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _check(hip_lib().fsea_host_alloc(n, ctypes.byref(self._ptr)))
+        buf = (ctypes.c_char * n).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            hip_lib().fsea_host_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
 
 
 def composite_max_device(d_dst, d_src, dst_x, dst_y, width, height, dst_stride, dst_height, src_stride, device=0,

@@ -132,8 +132,14 @@ int fsea_exec_u8_tiled_device(fsea_plan *plan, const void *d_iq, size_t n_frames
                               size_t image_rows, size_t image_stride, size_t first_x, size_t tile_rows,
                               size_t tile_step, void *stream);
 
-/* Host-buffer execution: copies through pinned staging, runs, copies back,
- * returns when `out` is complete. */
+/* Host-buffer execution; returns when `out` is complete.  Batches of up to 256 KiB (in + out: one nrf_fft_process
+ * row) run as ONE launch on device-mapped pinned staging.  Larger ones are pipelined in chunks of whole frames: chunk
+ * c travels to the device while chunk c-1 is transformed and the rows of chunk c-2 travel back, on three streams --
+ * the streaming shape of the reference's tools (c/fft-batch.c:54-102: a transfer in, a row out) at the granularity a
+ * PCIe link wants.  `iq` and `out` may be any host memory; pages that are not pinned yet are pinned in place for the
+ * duration of the call (hipHostRegister) so that the two directions overlap, and memory from fsea_host_alloc (or
+ * hipHostMalloc) skips that step.  Link-bound: 64 MiB in + 128 MiB out in 2.6-2.9 ms on an MI355X host
+ * (profiles/r03_host_path.txt).  The same holds for the _shifted_ and _f64_ forms below. */
 int fsea_exec_u8_host(fsea_plan *plan, const uint8_t *iq, size_t n_frames, int flip,
                       void *out);
 
@@ -191,6 +197,11 @@ int fsea_composite_max_device(void *d_dst, const void *d_src, uint32_t dst_x,
 int fsea_stitch_tiles_device(void *d_image, const void *d_tiles, uint32_t n_tiles, uint32_t first_x,
                              uint32_t width_step, uint32_t width, uint32_t height,
                              uint32_t image_stride, int device, void *stream);
+
+/* Pinned (page-locked) host memory for the buffers handed to the *_host entry points, so that C callers need no HIP
+ * headers: copies from and to it are asynchronous without a per-call registration.  Free with fsea_host_free. */
+int fsea_host_alloc(size_t bytes, void **ptr);
+int fsea_host_free(void *ptr);
 
 /* Small device-memory helpers so that C callers need no HIP headers. */
 int fsea_device_alloc(int device, size_t bytes, void **d_ptr);

@@ -20,7 +20,7 @@ VARIANTS = {
            "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na",
            "abl_io_nt_ws", "abl_io_nt_wl", "abl_io_nt_wls", "abl_ws", "abl_wl", "abl_wls", "abl_px_nolog", "abl_px_wide"],
     1024: ["", "cp0", "ldst_nt", "r1", "x0", "B", "C", "D"],
-    4096: ["", "nr", "cp0", "st_nt", "r1", "t256", "x0", "df", "B", "B3", "C", "D",
+    4096: ["", "w64", "s2", "nr", "cp0", "st_nt", "r1", "t256", "x0", "df", "B", "B3", "C", "D",
            "abl_px_nolog", "abl_px_nost", "abl_px_wide", "abl_px_io", "abl_px_io_wide"],
     32: [""], 64: [""], 128: ["", "p16"], 256: ["", "cp0", "ldst_nt", "p16"], 512: [""], 2048: ["", "nr", "cp0", "st_nt", "x0", "df", "B", "C"],
     16384: ["", "cp0", "st_nt", "r1", "nd", "B"],

@@ -18,12 +18,21 @@ thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 static thread_local std::barrier<> *g_barrier = nullptr;
 static thread_local std::barrier<> *g_wave_barrier = nullptr;
 static thread_local unsigned *g_wave_slot = nullptr;  // one word per wave for readfirstlane
+static thread_local unsigned *g_wave_lanes = nullptr; // 64 words per wave for the cross-lane reads
 void emu_syncthreads() { g_barrier->arrive_and_wait(); }
 void emu_wave_barrier() { g_wave_barrier->arrive_and_wait(); }
 unsigned emu_readfirstlane(unsigned v) {
     if ((threadIdx.x & 63) == 0) *g_wave_slot = v;
     g_wave_barrier->arrive_and_wait();
     const unsigned r = *g_wave_slot;
+    g_wave_barrier->arrive_and_wait();
+    return r;
+}
+
+unsigned fsea::emu_lane_read(unsigned v, int src_lane) {
+    g_wave_lanes[threadIdx.x & 63] = v;
+    g_wave_barrier->arrive_and_wait();
+    const unsigned r = g_wave_lanes[src_lane & 63];
     g_wave_barrier->arrive_and_wait();
     return r;
 }
@@ -60,6 +69,7 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
         constexpr int WAVES = (Cfg::WG + 63) / 64;
         std::vector<std::unique_ptr<std::barrier<>>> wbar;
         std::vector<unsigned> wslot(WAVES, 0);
+        std::vector<unsigned> wlanes(WAVES * 64, 0);
         for (int w = 0; w < WAVES; ++w) {
             wbar.emplace_back(new std::barrier<>(std::min(64, Cfg::WG - 64 * w)));
         }
@@ -73,6 +83,7 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
                 g_barrier = &bar;
                 g_wave_barrier = wbar[t / 64].get();
                 g_wave_slot = &wslot[t / 64];
+                g_wave_lanes = &wlanes[(t / 64) * 64];
                 fsea::FftKernel<Cfg, IN, MODE_T, ROT>::run(a, lds);
             });
         }
@@ -86,6 +97,17 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
 
 template <class Cfg>
 static int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsigned grid) {
+    constexpr bool U8_ONLY = (Cfg::OPT & 1048576) != 0;  // the W64 schedule has u8 kernels only
+    if constexpr (U8_ONLY) {
+        if (in_kind != fsea::IN_U8) return -3;
+    }
+    if constexpr (U8_ONLY) {
+        if (mode_t == fsea::MODE_MAG) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
+        else if (mode_t == fsea::MODE_DB5_U8_DCFIX) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX>(a, grid);
+        else if (mode_t == fsea::MODE_DB10_U8) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB10_U8>(a, grid);
+        else run_grid<Cfg, fsea::IN_U8, -1>(a, grid);
+        return 0;
+    } else
     if (in_kind == fsea::IN_U8_ROT) run_grid<Cfg, fsea::IN_U8, -1, true>(a, grid);
     else if (in_kind == fsea::IN_U8 && mode_t == fsea::MODE_MAG) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
     else if (in_kind == fsea::IN_U8 && mode_t == fsea::MODE_DB5_U8_DCFIX) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX>(a, grid);
@@ -152,6 +174,17 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     if (!v.empty()) {
 #define EMU_VARIANT(NN, NAME, CFG) \
     if (n == NN && v == NAME) return dispatch<fsea::FftCfg<CFG>>(in_kind, mt, a, grid);
+        EMU_VARIANT(4096, "w64", FSEA_CFG_4096_W64)
+        EMU_VARIANT(4096, "s2", FSEA_CFG_4096_S2)
+        EMU_VARIANT(4096, "w64b", FSEA_CFG_4096_W64B)
+        EMU_VARIANT(4096, "pk", FSEA_CFG_4096_PK)
+        EMU_VARIANT(4096, "px0", FSEA_CFG_4096_PX0)
+        EMU_VARIANT(8192, "pk", FSEA_CFG_8192_PK)
+        EMU_VARIANT(8192, "px0", FSEA_CFG_8192_PX0)
+        EMU_VARIANT(256, "pk", FSEA_CFG_256_PK)
+        EMU_VARIANT(256, "px0", FSEA_CFG_256_PX0)
+        EMU_VARIANT(1024, "px0", FSEA_CFG_1024_PX0)
+        EMU_VARIANT(256, "p64", FSEA_CFG_256_P64)
         EMU_VARIANT(8192, "B2", FSEA_CFG_8192_B2)
         EMU_VARIANT(8192, "D2", FSEA_CFG_8192_D2)
         EMU_VARIANT(8192, "W", FSEA_CFG_8192_W)

@@ -118,7 +118,9 @@ def test_edge_inputs():
                                        (8192, "notwl"), (8192, "notwr"), (4096, "nr"), (2048, "nr"), (8192, "twe"), (4096, "twe"), (1024, "twe"), (4096, "x0"), (4096, "df"), (4096, "r1"), (4096, "t256"), (4096, "B3"), (4096, "B"),
                                        (4096, "C"), (4096, "D"), (2048, "x0"), (2048, "df"), (2048, "B"), (2048, "C"),
                                        (1024, "r1"), (1024, "x0"), (1024, "B"), (1024, "C"), (1024, "D"),
-                                       (16384, "r1"), (16384, "nd"), (16384, "B"), (256, "p16"), (128, "p16")])
+                                       (16384, "r1"), (16384, "nd"), (16384, "B"), (256, "p16"), (128, "p16"),
+                                       (4096, "w64"), (4096, "w64b"), (4096, "s2"), (4096, "pk"), (4096, "px0"), (8192, "pk"), (8192, "px0"),
+                                       (256, "pk"), (256, "px0"), (1024, "px0"), (256, "p64")])
 def test_tuning_variants(n, variant):
     """Every kernel variant compiled into libfsea_hip_tune.so (fsea_plan_create_variant) stays correct."""
     nf = 9 if n <= 1024 else 3
@@ -192,3 +194,52 @@ def test_static_unit_interleave_of_the_multi_wave_sizes(n, nf, grid):
     for mode in (0, 2):
         got = emu_rows(iq, n, nf, mode=mode, grid=grid, dynamic_units=False)
         parity.check_mode(got, iq, n, nf, n, True, mode)
+
+
+@pytest.mark.parametrize("variant", ["w64", "w64b"])
+def test_single_wave_64x64_schedule(variant):
+    """FftKernel::run_w64 (tuning library): dword loads redistributed by v_permlane32_swap, one LDS exchange, deferred
+    last-pass twiddles, pixel rows transposed in quads -- compile-time and run-time-mode kernels, both byte conventions,
+    ragged grids, and the tiled (stitched-image) addressing."""
+    n = 4096
+    for nf, grid in ((1, 1), (5, 3), (4, 8)):
+        iq = synth_iq(64 + nf, 2 * nf * n)
+        for mode in (0, 1, 2):
+            for spec in (True, False):
+                got = emu_rows(iq, n, nf, mode=mode, grid=grid, specialised=spec, variant=variant)
+                parity.check_mode(got, iq, n, nf, n, True, mode)
+                if mode == 2:
+                    assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
+    iq = synth_iq(65, 2 * 3 * n) ^ np.uint8(0x80)
+    for mode in (0, 2, 3):
+        got = emu_rows(iq, n, 3, flip=False, mode=mode, specialised=False, variant=variant)
+        parity.check_mode(got, iq, n, 3, n, False, mode)
+    # overlapped frames (hop < N) and the tiled output
+    hop, nf = 1024, 6
+    iq = synth_iq(66, 2 * ((nf - 1) * hop + n))
+    got = emu_rows(iq, n, nf, hop=hop, mode=1, grid=2, variant=variant)
+    parity.check_mode(got, iq, n, nf, hop, True, 1)
+    tiles, tile_rows, first_x, step = 2, 3, 8, n + 12
+    nf = tiles * tile_rows
+    iq = synth_iq(67, 2 * nf * n)
+    rows = emu_rows(iq, n, nf, mode=2, grid=2, variant=variant)
+    shape = (tile_rows + 1, first_x + (tiles - 1) * step + n + 4)
+    image = emu_tiled(iq, n, nf, shape, first_x, tile_rows, step, mode=2, grid=2, fill=7, variant=variant)
+    want = np.full(shape, 7, dtype=np.uint8)
+    for k in range(tiles):
+        want[:tile_rows, first_x + k * step: first_x + k * step + n] = rows[k * tile_rows:(k + 1) * tile_rows]
+    assert np.array_equal(image, want)
+
+
+def test_biased_pixel_rounding_equals_truncation_on_a_dense_sweep():
+    """The product's pixel epilogue lets v_cvt_pk_u8_f32 round to nearest on d - (0.5 - 2^-25) instead of truncating d
+    (fsea_fft_core.h, OPT 4194304).  On a dense sweep of d over the pixel range the two differ only where d lies within
+    ~1e-5 above an odd integer."""
+    d = np.linspace(-3.0, 260.0, 4_000_001).astype(np.float32)
+    biased = np.clip(np.rint((d.astype(np.float64) - 0.49999997).astype(np.float32)), 0, 255)
+    trunc = np.clip(np.trunc(d), 0, 255)
+    diff = biased != trunc
+    assert diff.mean() < 1e-4
+    assert np.all(np.abs(biased - trunc)[diff] == 1)
+    frac = d[diff] - np.floor(d[diff])
+    assert np.all(frac < 2e-5)
