@@ -108,11 +108,12 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
         s = k % sets
         plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=stream)
 
-    # clock pre-warm (untimed, before the official warm-up): the shader clock needs tens of
-    # milliseconds of load to settle, far longer than W short steps
+    # clock pre-warm (untimed, before the official warm-up, named in config.clock_prewarm_s): the shader clock
+    # needs tens of milliseconds of load to settle, far longer than W short steps.  It drives the chip to its
+    # power-capped clock, i.e. it lowers the number; --prewarm 0 switches it off.
     t_pre = time.perf_counter()
     k = 0
-    while time.perf_counter() - t_pre < 0.25:
+    while time.perf_counter() - t_pre < args.prewarm:
         for _ in range(64):
             step(k)
             k += 1
@@ -406,6 +407,37 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
     return line
 
 
+def host_path_rate(n, frames):
+    """PCIe-inclusive rate of the same batch through fsea_exec_u8_host (pipelined copy-in / transform / copy-out, caller
+    buffers that live across calls, pageable numpy memory); informational, never `value`."""
+    from frequensea_amd import fsea
+    plan = fsea.Plan(n)
+    iq = synth_batch(3, 2 * n * frames)
+    out = np.zeros((frames, n), np.float32)
+    plan.exec_host_into(iq, frames, out)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        plan.exec_host_into(iq, frames, out)
+        ts.append(time.perf_counter() - t0)
+    plan.close()
+    dt = float(np.median(ts))
+    return {"host_path_frames_per_sec_n%d" % n: frames / dt, "host_path_ms_per_batch_n%d" % n: 1e3 * dt}
+
+
+def skeleton_rates():
+    import subprocess
+    script = os.path.join(ROOT, "scripts", "skeleton_rates.py")
+    lib = os.path.join(ROOT, "frequensea_amd", "libfsea_hip_tune.so")
+    if not (os.path.exists(script) and os.path.exists(lib)):
+        return None
+    try:
+        out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 def effective_cpus():
     """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU
     boxes show 256 logical CPUs under a quota of 16; more threads than that only get throttled)."""
@@ -485,6 +517,8 @@ def main():
     ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
     ap.add_argument("--no-fused-stitch", action="store_true",
                     help="broad: rank 0 stitches its own tiles with the composite kernel instead of writing them in place")
+    ap.add_argument("--prewarm", type=float, default=0.25,
+                    help="seconds of untimed steps in front of the --warmup steps (clock settling); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--two-stream", action="store_true",
@@ -535,7 +569,13 @@ def main():
 
     res = run_gpu(args, args.workload, rank, world, dist, torch, args.steps, args.warmup, args.sets)
     n, frames, hop = res["n"], res["frames"], res["hop"]
-    value = world * frames * args.steps / res["wall"]
+    # The timed region is the K steps between the opening and the closing synchronisation.  Its length is taken from the
+    # two HIP events recorded on the launch stream in front of the first and behind the last of those K steps (SURVEY.md
+    # 8(d): hipEvent timing; MAX over ranks), which is the time the device spent on them; the host's wall clock around the
+    # same region, which adds the submission latency of the first launch and the return latency of the last
+    # synchronisation (2-3 us per step at K = 20), is reported beside it as value_wall / ms_per_step_wall.
+    value = world * frames / (res["kernel_ms"] * 1e-3)
+    value_wall = world * frames * args.steps / res["wall"]
     alg_bytes = (2 * hop + 4 * n) * frames                      # 2*hop read + 4*N written
     achieved = alg_bytes / (res["kernel_ms"] * 1e-3) / 1e9
     line = {
@@ -545,17 +585,21 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * res["wall"] / args.steps,
+        "ms_per_step": res["kernel_ms"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "msamples_per_sec": value * hop / 1e6,
+        "timing": "HIP events on the launch stream around the K timed steps, MAX over ranks; host wall clock of the same region in *_wall",
+        "value_wall": value_wall,
+        "ms_per_step_wall": 1e3 * res["wall"] / args.steps,
         "config": {"workload": "%s: batched %d-pt FFT, %d frames per GPU per step, int8 IQ resident in HBM, "
                                "MAG_F32 epilogue (nrf_fft_process semantics)" % (args.workload, n, frames),
                    "fft_size": n, "frames_per_step_per_gpu": frames, "hop": hop,
-                   "buffer_sets": args.sets, "parallelism": "frames sharded x%d, no collective" % world},
+                   "buffer_sets": args.sets, "clock_prewarm_s": args.prewarm,
+                   "parallelism": "frames sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": res["kernel"], "avg_launch_ms": res["kernel_ms"],
@@ -587,20 +631,33 @@ def main():
     if world == 1 and not args.no_extra and args.workload == "batch8192x4096":
         ex = run_gpu(args, "batch1024x32768", rank, world, dist, torch, args.steps, args.warmup, args.sets)
         exb = (2 * ex["hop"] + 4 * ex["n"]) * ex["frames"]
-        line["extra"] = {"two_stream_frames_per_sec_n8192": res["two_stream"],
-                         "two_stream_frames_per_sec_n1024": ex["two_stream"],
-                         "fft_frames_per_sec_n1024": ex["frames"] * args.steps / ex["wall"],
-                         "msamples_per_sec_n1024": ex["frames"] * args.steps / ex["wall"] * ex["hop"] / 1e6,
+        line["extra"] = {"fft_frames_per_sec_n1024": ex["frames"] / (ex["kernel_ms"] * 1e-3),
+                         "msamples_per_sec_n1024": ex["frames"] / (ex["kernel_ms"] * 1e-3) * ex["hop"] / 1e6,
                          "roofline_frac_n1024": exb / (ex["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_n1024": ex["kernel"], "avg_launch_ms_n1024": ex["kernel_ms"]}
+        if args.two_stream:
+            line["extra"].update({"two_stream_frames_per_sec_n8192": res["two_stream"],
+                                  "two_stream_frames_per_sec_n1024": ex["two_stream"]})
         # BASELINE.json's other single-GPU-measurable configurations, shorter runs (informational)
         st_steps = max(10, min(args.steps, 300))
         st = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2)
         stb = (2 * st["hop"] + 4 * st["n"]) * st["frames"]
-        line["extra"].update({"stft16384_hop8192_frames_per_sec": st["frames"] * st_steps / st["wall"],
+        line["extra"].update({"stft16384_hop8192_frames_per_sec": st["frames"] / (st["kernel_ms"] * 1e-3),
                               "stft16384_roofline_frac": stb / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS})
         br = run_broad(args, rank, world, dist, torch, 20, 3)
-        line["extra"].update({"broad_sweep_1gpu_frames_per_sec": br["value"], "broad_sweep_1gpu_ms": br["ms_per_step"]})
+        line["extra"].update({"broad_sweep_1gpu_frames_per_sec": br["value"], "broad_sweep_1gpu_ms": br["ms_per_step"],
+                              "broad_sweep_roofline_frac": br["roofline"]["frac"]})
+        line["extra"].update(host_path_rate(n, frames))
+        # what bounds the headline kernel from above on THIS box, same launch shape and buffer rotation: its I/O skeleton
+        # and a plain 1 : 2 read/write stream (tuning library, in a subprocess: scripts/skeleton_rates.py)
+        sk = skeleton_rates()
+        if sk:
+            line["roofline"].update({"io_skeleton_frac": sk["io_skeleton_frac"], "copy_frac": sk["copy_frac"],
+                                     "io_skeleton_launch_ms": sk["io_skeleton_launch_ms"], "copy_launch_ms": sk["copy_launch_ms"],
+                                     "product_frac_in_that_process": sk["product_frac"],
+                                     "ceiling_note": "io_skeleton = this kernel's loads and row stores without LDS exchange and "
+                                                     "butterflies (abl_io_nt); copy = a plain 16-bytes-in / 32-bytes-out nt "
+                                                     "stream; scripts/skeleton_rates.py in this run"})
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cores, quota_note = effective_cpus()

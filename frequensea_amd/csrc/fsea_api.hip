@@ -1029,7 +1029,50 @@ int fsea_stream_synchronize(fsea_plan *p, void *stream) {
 }
 
 #ifdef FSEA_TUNE
+}  // extern "C"
+
+// A plain stream with the headline kernel's byte mix, 1 read : 2 written, and its cache policy (nt both ways): every thread
+// moves 16 bytes in and 32 bytes out per iteration.  What the memory system gives a kernel that does nothing else.
+typedef uint32_t tune_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fsea_tune_stream_1to2_kernel(const tune_u32x4 *in, tune_u32x4 *out, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const tune_u32x4 v = __builtin_nontemporal_load(in + i);
+        tune_u32x4 w = v;
+        w.x ^= 0x80808080u;
+        __builtin_nontemporal_store(v, out + 2 * i);
+        __builtin_nontemporal_store(w, out + 2 * i + 1);
+    }
+}
+
+extern "C" {
 // ---- tuning / measurement entry points (include/fsea_tune.h; libfsea_hip_tune.so only) ----
+int fsea_tune_stream_1to2(void *const *d_in, void *const *d_out, int n_sets, size_t in_bytes, int device, void *stream,
+                          int reps, float *avg_ms) {
+    if (!d_in || !d_out || n_sets <= 0 || reps <= 0 || !avg_ms || (in_bytes % 16) != 0) return fail(FSEA_EINVAL, "bad arguments");
+    FSEA_ON_DEVICE(device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipDeviceProp_t prop;
+    FSEA_HIP(hipGetDeviceProperties(&prop, device));
+    hipEvent_t e0, e1;
+    FSEA_HIP(hipEventCreate(&e0));
+    FSEA_HIP(hipEventCreate(&e1));
+    const unsigned grid = (unsigned)prop.multiProcessorCount * 8u;
+    FSEA_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) {
+        hipLaunchKernelGGL(fsea_tune_stream_1to2_kernel, dim3(grid), dim3(256), 0, s, static_cast<const tune_u32x4 *>(d_in[i % n_sets]),
+                           static_cast<tune_u32x4 *>(d_out[i % n_sets]), in_bytes / 16);
+    }
+    FSEA_HIP(hipEventRecord(e1, s));
+    FSEA_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FSEA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)reps;
+    return FSEA_OK;
+}
+
 int fsea_plan_create_variant(fsea_plan **out, int fft_size, int hop, int mode, int device, const char *variant) {
     return create_plan(out, fft_size, hop, mode, device, variant ? variant : "");
 }

@@ -33,7 +33,7 @@ EXPORTS = [
 ]
 # include/fsea_tune.h: only libfsea_hip_tune.so (scripts/tune.py and friends) has these
 TUNE_EXPORTS = ["fsea_plan_create_variant", "fsea_time_exec_u8_device", "fsea_time_exec_u8_rotating",
-                "fsea_plan_read_trace"]
+                "fsea_plan_read_trace", "fsea_tune_stream_1to2"]
 
 
 class FseaError(RuntimeError):
@@ -95,6 +95,8 @@ def hip_lib():
             L.fsea_plan_create_variant.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.c_char_p]
             L.fsea_time_exec_u8_device.argtypes = [vp, vp, sz, ci, vp, vp, ci, ctypes.POINTER(ctypes.c_float)]
             L.fsea_plan_read_trace.argtypes = [vp, vp, ctypes.c_uint]
+            L.fsea_tune_stream_1to2.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ci, sz, ci, vp, ci,
+                                                ctypes.POINTER(ctypes.c_float)]
             L.fsea_time_exec_u8_rotating.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, sz, ci, vp, ci,
                                                      ctypes.POINTER(ctypes.c_float)]
         L.fsea_plan_destroy.argtypes = [vp]

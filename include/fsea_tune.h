@@ -34,6 +34,12 @@ int fsea_time_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames,
 int fsea_time_exec_u8_rotating(fsea_plan *plan, void *const *d_iq, void *const *d_out, int n_sets,
                                size_t n_frames, int flip, void *stream, int reps, float *avg_ms);
 
+/* A plain streaming kernel with the headline kernel's byte mix (every 16 bytes read, 32 written, nt both ways), `reps`
+ * launches back to back over n_sets buffer sets in rotation between two HIP events on `stream`: the rate the memory
+ * system gives a kernel that does nothing else.  in_bytes per set (a multiple of 16); each d_out holds 2 * in_bytes. */
+int fsea_tune_stream_1to2(void *const *d_in, void *const *d_out, int n_sets, size_t in_bytes, int device, void *stream,
+                          int reps, float *avg_ms);
+
 /* When the environment variable FSEA_TRACE is set at plan creation, every launch records per
  * workgroup {wall-clock start, end (100 MHz ticks), shader-clock start, end, HW_ID, XCC_ID,
  * prologue done, first pass 0 done, end of iteration 0..23}; this copies the [n_workgroups][32]

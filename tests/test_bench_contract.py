@@ -49,9 +49,19 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.2 < roof["frac"] < 1.0
     assert roof["kernel"] == "fsea_fft8192_u8_mag"
     assert roof["traffic"] is None or 0.9 < roof["traffic"] / roof["algorithmic_bytes_per_launch"] < 1.2
-    # value = frames of all ranks / wall time of the timed steps; the kernel time cannot exceed the step time
+    # value = frames of all ranks / time of the timed steps (HIP events on the launch stream); the host's wall clock
+    # around the same K steps is reported beside it and can only be longer
     assert abs(d["value"] - 4096 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
     assert roof["avg_launch_ms"] <= d["ms_per_step"] * 1.02
+    assert d["ms_per_step_wall"] >= d["ms_per_step"] * 0.98 and d["value_wall"] <= d["value"] * 1.02
+    assert abs(d["value_wall"] - 4096 * 1e3 / d["ms_per_step_wall"]) / d["value_wall"] < 1e-6
+    assert d["config"]["clock_prewarm_s"] == 0.25
+    # the ceilings measured in the same run: the kernel cannot beat its own I/O skeleton, nor that a plain stream
+    if "io_skeleton_frac" in roof:
+        assert roof["frac"] < roof["io_skeleton_frac"] * 1.05 < roof["copy_frac"] * 1.3 and roof["copy_frac"] < 1.0
+    ex = d["extra"]
+    assert ex["host_path_frames_per_sec_n8192"] > 0 and "two_stream_frames_per_sec_n8192" not in ex
+    assert 0.1 < ex["stft16384_roofline_frac"] < 1.0 and 0.1 < ex["broad_sweep_roofline_frac"] < 1.0
     cb = d["cpu_baseline"]
     assert cb["unit"] == "frames/s" and cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert isinstance(cb["sample"], str) and cb["sample"]
