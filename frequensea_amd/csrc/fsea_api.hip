@@ -247,8 +247,13 @@ struct fsea_plan {
     // needs exactly one; launches on different streams may overlap and never share one.
     unsigned *d_ctr = nullptr;  // FSEA_CTR_SLOTS x FSEA_CTR_WORDS
     std::mutex slot_mu;
-    hipStream_t slot_stream[FSEA_CTR_SLOTS] = {};
-    unsigned n_slots = 0;
+    struct CtrSlot {
+        hipStream_t stream = nullptr;   // the stream the slot serves (meaningful while `used` and not `anonymous`)
+        hipEvent_t ev = nullptr;        // recorded behind the slot's last launch (not while the stream is being captured)
+        bool used = false, pending = false, anonymous = false, captured = false;
+        unsigned long long seq = 0;     // launch order, for least-recently-used recycling
+    } slots[FSEA_CTR_SLOTS];
+    unsigned long long slot_seq = 0;
     unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics (tuning library)
     int occ[fsea::K_COUNT] = {0, 0, 0, 0, 0, 0};
     // FSEA_UNITS_AUTO: launches with at most FSEA_STATIC_UNITS_PER_WG units per workgroup use the static interleave,
@@ -316,16 +321,69 @@ unsigned grid_for(const fsea_plan *p, const fsea::KernelEntry *e, int occ, size_
     return (unsigned)g;
 }
 
-// the ticket-counter slot of `s` (see fsea_plan::d_ctr), or null when the plan is already in use on
-// FSEA_CTR_SLOTS other streams
-unsigned *counter_slot(fsea_plan *p, hipStream_t s) {
+// The ticket-counter slot for a launch on stream `s` that uses the counters (see fsea_plan::d_ctr).
+//  * A stream keeps its slot: launches on one stream run in order and the last workgroup of a launch zeroes the slot.
+//  * A slot is handed to another stream once the event recorded behind its last launch has completed (least recently
+//    used first), so a plan may see any number of short-lived streams over its lifetime; with FSEA_CTR_SLOTS launches in
+//    flight on as many streams, the call waits for the oldest of them instead of failing.
+//  * A stream handle that matches a slot whose last launch is still running is either that stream (already ordered) or a
+//    new stream that got a destroyed stream's handle: the launch is ordered behind the slot's event either way.
+//  * hipStreamPerThread names a different stream in every thread: it never keeps a slot, every launch takes a free one.
+//  * While `s` is being captured into a graph nothing but the kernel may be enqueued: no event; the slot then stays
+//    with that stream handle for good (replay one instance of such a graph at a time, include/fsea.h).
+// Returns null only if an event cannot be created or every slot belongs to a captured stream.
+unsigned *counter_slot(fsea_plan *p, hipStream_t s, int *index, bool *record) {
     std::lock_guard<std::mutex> lock(p->slot_mu);
-    for (unsigned i = 0; i < p->n_slots; ++i) {
-        if (p->slot_stream[i] == s) return p->d_ctr + FSEA_CTR_WORDS * i;
+    bool capturing = false;
+    if (s != nullptr) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess) capturing = (st == hipStreamCaptureStatusActive);
+        else (void)hipGetLastError();
     }
-    if (p->n_slots == FSEA_CTR_SLOTS) return nullptr;
-    p->slot_stream[p->n_slots] = s;
-    return p->d_ctr + FSEA_CTR_WORDS * p->n_slots++;
+    const bool anonymous = (s == hipStreamPerThread);
+    int pick = -1;
+    if (!anonymous) {
+        for (unsigned i = 0; i < FSEA_CTR_SLOTS; ++i) {
+            if (p->slots[i].used && !p->slots[i].anonymous && p->slots[i].stream == s) pick = (int)i;
+        }
+        if (pick >= 0 && p->slots[pick].pending && !capturing) {
+            if (hipStreamWaitEvent(s, p->slots[pick].ev, 0) != hipSuccess) (void)hipGetLastError();
+        }
+    }
+    if (pick < 0) {
+        for (unsigned i = 0; i < FSEA_CTR_SLOTS && pick < 0; ++i) {
+            if (!p->slots[i].used) pick = (int)i;
+        }
+        int oldest = -1;
+        for (unsigned i = 0; i < FSEA_CTR_SLOTS && pick < 0; ++i) {
+            fsea_plan::CtrSlot &c = p->slots[i];
+            if (c.captured) continue;
+            if (!c.pending || hipEventQuery(c.ev) == hipSuccess) {
+                if (pick < 0 || c.seq < p->slots[pick].seq) pick = (int)i;
+            } else {
+                (void)hipGetLastError();  // hipErrorNotReady is not an error
+                if (oldest < 0 || c.seq < p->slots[oldest].seq) oldest = (int)i;
+            }
+        }
+        if (pick < 0 && oldest >= 0) {  // FSEA_CTR_SLOTS launches in flight: wait for the oldest one
+            if (hipEventSynchronize(p->slots[oldest].ev) != hipSuccess) return nullptr;
+            pick = oldest;
+        }
+        if (pick < 0) return nullptr;
+        p->slots[pick].used = true;
+        p->slots[pick].pending = false;
+        p->slots[pick].anonymous = anonymous;
+        p->slots[pick].stream = s;
+    }
+    fsea_plan::CtrSlot &c = p->slots[pick];
+    if (capturing) c.captured = true;
+    if (!capturing && !c.ev) {
+        if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    c.seq = ++p->slot_seq;
+    *index = pick;
+    *record = !capturing;
+    return p->d_ctr + (size_t)FSEA_CTR_WORDS * (size_t)pick;
 }
 
 // where the rows of a launch go when they are tiles of an image (fsea_exec_u8_tiled_device); rows == 0: contiguous
@@ -358,10 +416,6 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     a.hop = (size_t)p->hop;
     a.xormask = flip ? 0u : 0x80808080u;
     a.mode = mode;
-    a.ctr = counter_slot(p, s);
-    if (!a.ctr) {
-        return fail(FSEA_EINVAL, "plan is already in use on %u streams; create another plan for more", FSEA_CTR_SLOTS);
-    }
     a.trace = p->d_trace;
     for (int i = 0; i < 4; ++i) a.tw[i] = p->d_tw + p->tw_off[i];
     a.tw_small = p->d_tw;
@@ -380,8 +434,22 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
         a.pitch_tile = tiles->pitch_tile;
         a.out_span = tiles->span;
     }
+    // only a launch that hands its frames out by the ticket pools needs a counter slot (single-wave sizes and short
+    // launches never touch the counters)
+    int slot = -1;
+    bool record = false;
+    a.ctr = p->d_ctr;
+    if (e->counters == 2 || (e->counters == 1 && a.dynamic_units != 0)) {
+        a.ctr = counter_slot(p, s, &slot, &record);
+        if (!a.ctr) return fail(FSEA_EHIP, "no ticket-counter slot for this launch (event creation failed, or %u captured streams)", FSEA_CTR_SLOTS);
+    }
     e->launch(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
     FSEA_HIP(hipGetLastError());
+    if (slot >= 0 && record) {
+        std::lock_guard<std::mutex> lock(p->slot_mu);
+        FSEA_HIP(hipEventRecord(p->slots[slot].ev, s));
+        p->slots[slot].pending = true;
+    }
     return FSEA_OK;
 }
 
@@ -505,7 +573,7 @@ int fsea_plan_reset(fsea_plan *p) {
     FSEA_HIP(hipDeviceSynchronize());
     {
         std::lock_guard<std::mutex> lock(p->slot_mu);
-        p->n_slots = 0;
+        for (auto &c : p->slots) c.used = c.pending = c.anonymous = c.captured = false;
     }
     return FSEA_OK;
 }
@@ -523,6 +591,9 @@ int fsea_plan_destroy(fsea_plan *p) {
     if (p->h_out) (void)hipHostFree(p->h_out);
     if (p->d_trace) (void)hipFree(p->d_trace);
     if (p->d_ctr) (void)hipFree(p->d_ctr);
+    for (auto &c : p->slots) {
+        if (c.ev) (void)hipEventDestroy(c.ev);
+    }
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     for (unsigned c = 0; c < FSEA_HOST_CHUNKS_MAX; ++c) {
@@ -781,6 +852,7 @@ int fsea_exec_f64_host(fsea_plan *p, const double *iq, size_t n_frames, void *ou
 
 struct fsea_history {
     fsea_plan *plan = nullptr;
+    int device = 0;           // the plan's device (fsea_history_destroy must not need the plan any more)
     int rows = 0;
     int head = 0;             // ring row holding the newest spectrum
     int cur = 0;              // which of the two storages is live (nrf_fft_shift works out of place)
@@ -828,6 +900,7 @@ int fsea_history_create(fsea_plan *p, int rows, fsea_history **out) {
     fsea_history *h = new (std::nothrow) fsea_history();
     if (!h) return fail(FSEA_ENOMEM, "out of host memory");
     h->plan = p;
+    h->device = p->device;
     h->rows = rows;
     const size_t bytes = (size_t)rows * (size_t)p->n * sizeof(float);
     hipError_t he = hipMalloc(reinterpret_cast<void **>(&h->d_ring[0]), bytes);
@@ -846,7 +919,7 @@ int fsea_history_create(fsea_plan *p, int rows, fsea_history **out) {
 
 int fsea_history_destroy(fsea_history *h) {
     if (!h) return FSEA_OK;
-    DeviceGuard device_guard_(h->plan->device);
+    DeviceGuard device_guard_(h->device);
     if (h->d_ring[0]) (void)hipFree(h->d_ring[0]);
     if (h->d_ring[1]) (void)hipFree(h->d_ring[1]);
     if (h->h_stage) (void)hipHostFree(h->h_stage);

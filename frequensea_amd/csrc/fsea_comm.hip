@@ -88,10 +88,19 @@ int fsea_comm_create(fsea_comm **out, int n_members, const int *devices) {
         c->comms.resize(n_members);
         ncclResult_t r = ncclCommInitAll(c->comms.data(), n_members, c->devices.data());
         if (r != ncclSuccess) {
-            delete c;
-            return fail("ncclCommInitAll failed: %s", ncclGetErrorString(r));
+            // FSEA_COMM_BACKEND=rccl insists; otherwise the gather still works over event-ordered peer copies, and says so
+            if (env && std::strcmp(env, "rccl") == 0) {
+                delete c;
+                return fail("ncclCommInitAll failed: %s", ncclGetErrorString(r));
+            }
+            std::fprintf(stderr, "fsea_comm: *** ncclCommInitAll over %d devices FAILED (%s): falling back to the \"copy\" backend "
+                                 "(hipMemcpyPeerAsync); set FSEA_COMM_BACKEND=rccl to make this fatal ***\n",
+                         n_members, ncclGetErrorString(r));
+            c->comms.clear();
+            c->rccl = false;
         }
-    } else {
+    }
+    if (!c->rccl) {
         for (int m = 0; m < n_members; ++m) {
             if (hipSetDevice(devices[m]) != hipSuccess ||
                 hipEventCreateWithFlags(&c->posts[m].ready, hipEventDisableTiming) != hipSuccess) {

@@ -395,7 +395,8 @@ __device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(flo
 // launches: lanes 12-15 of a row held Im(X)^2 of the NEXT row's bin, the v_mul_f32 that begins the next row's re^2 + im^2
 // (scripts/soak.py found it; profiles/r02_store_data_hazard.txt).  Sixteen wait states are spent behind every 16-byte
 // store, fenced so that the scheduler cannot move the next writer in front of them.
-// FSEA_STORE_GUARD: 1 = that (default), 0 = nothing (the pre-fix code, for the regression evidence), 2 = two 8-byte
+// FSEA_STORE_GUARD: 1 = that (default), 0 = nothing (the pre-fix code, for the regression evidence: such a build fails
+// tests/test_shipped_artifacts.py without a GPU and tests/test_gpu_soak.py / test_gpu_parity.py on one), 2 = two 8-byte
 // stores instead (no hazard by construction; 3-20 % slower at those sizes).
 #ifndef FSEA_STORE_GUARD
 #define FSEA_STORE_GUARD 1
@@ -414,6 +415,24 @@ __device__ __forceinline__ void store_data_guard() {
 #endif
 }
 
+// THE 16-byte buffer store of these kernels: store + its wait states, one primitive.  Nothing else in the kernel source may
+// emit a buffer_store_dwordx3/x4 -- the raw builtin is poisoned right below, so a new store form that bypasses the guard
+// does not compile (hipcc; the CPU shim of tests/emu has no hazard and no poison), and tests/test_shipped_artifacts.py
+// checks the disassembly of every shipped code object for the wait states behind every 12- and 16-byte store.
+template <int AUX>
+__device__ __forceinline__ void bst128(rsrc_t rs, uint32_t voff, uint32_t soff, u32x4 data) {
+#if FSEA_STORE_GUARD == 2
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{data[0], data[1]}, rs, voff, soff, AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{data[2], data[3]}, rs, voff + 8, soff, AUX);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(data, rs, voff, soff, AUX);
+    store_data_guard();
+#endif
+}
+#if defined(__HIP__)
+#pragma GCC poison __builtin_amdgcn_raw_buffer_store_b128 __builtin_amdgcn_raw_buffer_store_b96
+#endif
+
 // C consecutive f32 / u8 / complex outputs at byte offset voff (+ scalar soff)
 // AUX: cache-policy bits of the buffer instruction (0 = default, 2 = nt: streaming, do not keep)
 template <int C, int AUX = 0>
@@ -424,16 +443,7 @@ __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, con
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0]), f2u(v[1])}, rs, voff, soff, AUX);
     } else {
 #pragma unroll
-        for (int c = 0; c < C; c += 4) {
-#if FSEA_STORE_GUARD == 2
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c]), f2u(v[c + 1])}, rs, voff + 4 * c, soff, AUX);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c + 2]), f2u(v[c + 3])}, rs, voff + 4 * c + 8, soff, AUX);
-#else
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c]), f2u(v[c + 1]), f2u(v[c + 2]), f2u(v[c + 3])}, rs,
-                                                   voff + 4 * c, soff, AUX);
-            store_data_guard();
-#endif
-        }
+        for (int c = 0; c < C; c += 4) bst128<AUX>(rs, voff + 4 * c, soff, u32x4{f2u(v[c]), f2u(v[c + 1]), f2u(v[c + 2]), f2u(v[c + 3])});
     }
 }
 
@@ -459,16 +469,7 @@ __device__ __forceinline__ void bst(rsrc_t rs, uint32_t voff, uint32_t soff, con
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[0][0]), f2u(v[0][1])}, rs, voff, soff, AUX);
     } else {
 #pragma unroll
-        for (int c = 0; c < C; c += 2) {
-#if FSEA_STORE_GUARD == 2
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c][0]), f2u(v[c][1])}, rs, voff + 8 * c, soff, AUX);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{f2u(v[c + 1][0]), f2u(v[c + 1][1])}, rs, voff + 8 * c + 8, soff, AUX);
-#else
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{f2u(v[c][0]), f2u(v[c][1]), f2u(v[c + 1][0]), f2u(v[c + 1][1])},
-                                                   rs, voff + 8 * c, soff, AUX);
-            store_data_guard();
-#endif
-        }
+        for (int c = 0; c < C; c += 2) bst128<AUX>(rs, voff + 8 * c, soff, u32x4{f2u(v[c][0]), f2u(v[c][1]), f2u(v[c + 1][0]), f2u(v[c + 1][1])});
     }
 }
 
@@ -969,6 +970,9 @@ struct FftKernel {
             } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
                 for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);
+                // three adjacent dword stores (CL = 4) are merged into ONE buffer_store_dwordx3 by the compiler -- the same
+                // hazard as the 16-byte store (tests/test_shipped_artifacts.py found it in two tuning variants): guarded too
+                if constexpr (CL >= 4) store_data_guard();
             } else {
                 bst<CL, st_aux<4>()>(out, voff, soff, m);
             }
@@ -1007,6 +1011,12 @@ struct FftKernel {
     };
 
     static constexpr bool V2 = (Cfg::OPT & 64) != 0;
+    // what a launch does with FftArgs::ctr (host side: which launches need a ticket-counter slot, fsea_api.hip)
+    static constexpr int counters_used() {
+        if ((Cfg::OPT & 1048576) != 0) return 0;                     // W64: one wave per frame, static interleave
+        if (V2 || (Cfg::OPT & 262144) != 0) return 2;
+        return DYNAMIC ? 1 : 0;
+    }
 
     static constexpr bool W64 = (Cfg::OPT & 1048576) != 0;
 

@@ -23,6 +23,8 @@ struct KernelEntry {
     int radix[4];
     size_t lds_bytes;
     int c0;                // samples per pass-0 load (hop must be a multiple)
+    int counters;          // ticket counters: 0 = never used (single-wave frames), 1 = by launches with FftArgs::dynamic_units,
+                           // 2 = by every launch (the V2 schedule and the progress-word experiments of the tuning library)
     const void *fn[K_COUNT];    // __global__ function addresses (occupancy queries); null = not compiled
     const char *name[K_COUNT];  // symbol names as rocprof shows them
     void (*launch)(int kind, const FftArgs &args, unsigned grid, hipStream_t stream);
@@ -43,7 +45,8 @@ struct KernelEntry {
 #define FSEA_KERNEL_ENTRY_HEAD_(NAME, VARIANT)                                                        \
     NAME##_cfg::N, VARIANT, NAME##_cfg::T, NAME##_cfg::FPW, NAME##_cfg::WG, NAME##_cfg::NP,           \
         {NAME##_cfg::R(0), NAME##_cfg::R(1), NAME##_cfg::R(2), NAME##_cfg::R(3)},                     \
-        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC, NAME##_cfg::C(0)
+        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC, NAME##_cfg::C(0),                                   \
+        fsea::FftKernel<NAME##_cfg, fsea::IN_U8>::counters_used()
 
 // Defines the six __global__ entry points of one configuration, with plain C names so that
 // profiles are easy to read, and the launch trampoline + KernelEntry for it.
@@ -76,8 +79,10 @@ struct KernelEntry {
             &NAME##_launch};                                                                          \
     }
 
-// Tuning variants (libfsea_hip_tune.so only): the MAG kernel and the run-time-mode kernel; the
-// other kinds of such a plan fall back to the product configuration of the size.
+// Tuning variants (libfsea_hip_tune.so only): the MAG kernel and the run-time-mode kernel.  The pixel modes of such a
+// plan run the run-time-mode kernel; its f32-input and frequency-shifted kinds do not exist (launch() fails with
+// FSEA_EINVAL).  The V2 schedule (OPT 64) always hands its frames out by the ticket pools: fsea_plan_set_unit_distribution
+// has no effect on a V2 variant.
 #define FSEA_DEFINE_KERNEL_LITE(NAME, VARIANT, ...)                                                   \
     using NAME##_cfg = fsea::FftCfg<__VA_ARGS__>;                                                     \
     FSEA_KERNEL_FN_(NAME, _u8_mag, fsea::IN_U8, fsea::MODE_MAG)                                       \

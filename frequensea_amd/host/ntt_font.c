@@ -467,7 +467,8 @@ void ntt_font_measure(const ntt_font *font, const char *text, const int x, const
         ntt_font_hmetrics(font, g, &advance, &lsb);
         *width += (int)((float)advance * font_scale);
         if (text[ch + 1]) {
-            *width += (int)(font_scale * (float)ntt_font_kern_advance(font, g, ntt_font_glyph_index(font, (unsigned char)text[ch + 1])));
+            /* `*width += font_scale * kern` on an int (c/fft-stitch.c:118): the SUM is truncated, not the addend */
+            *width = (int)((float)*width + font_scale * (float)ntt_font_kern_advance(font, g, ntt_font_glyph_index(font, (unsigned char)text[ch + 1])));
         }
     }
 }
@@ -502,7 +503,8 @@ void ntt_font_draw(const ntt_font *font, uint8_t *img, const uint32_t img_stride
         }
         pen += (int)((float)advance * font_scale);
         if (text[ch + 1]) {
-            pen += (int)(font_scale * (float)ntt_font_kern_advance(font, g, ntt_font_glyph_index(font, (unsigned char)text[ch + 1])));
+            /* `_x += font_scale * kern` on an int (c/fft-stitch.c:152): the sum is truncated */
+            pen = (int)((float)pen + font_scale * (float)ntt_font_kern_advance(font, g, ntt_font_glyph_index(font, (unsigned char)text[ch + 1])));
         }
     }
 }

@@ -91,7 +91,8 @@ int fsea_plan_fft_size(const fsea_plan *plan);
 
 /* How a launch's frames are handed to the persistent workgroups of the sizes whose frames span several wavefronts
  * (4096 points and up): FSEA_UNITS_TICKETS = atomic ticket pools per XCD with stealing (evens out unequal progress;
- * best from about 32 frames per workgroup), FSEA_UNITS_STATIC = unit k of workgroup b is b + k * grid (no atomics;
+ * best from more than 16 units -- frames, pairs of frames at 4096 points -- per workgroup, which is where AUTO
+ * switches), FSEA_UNITS_STATIC = unit k of workgroup b is b + k * grid (no atomics;
  * best for short launches), FSEA_UNITS_AUTO (default) = chosen per launch by its length.  Results are identical; the
  * setting exists for measurements and tests.  Takes effect from the next launch; not to be changed while another
  * thread is launching the plan. */
@@ -108,11 +109,13 @@ int fsea_plan_set_unit_distribution(fsea_plan *plan, int policy);
  * stream: hipStream_t as void*; NULL is HIP's null (default) stream, which is
  * also what torch.cuda.current_stream().cuda_stream is unless a side stream
  * is current.  Asynchronous with respect to the host.
- * A plan may be launched from several host threads and on up to 64 different streams; launches on
- * one stream run in order, launches on different streams may overlap.  The calls leave the
- * caller's current HIP device unchanged.
- * The call enqueues exactly one kernel and nothing else, so it may be stream-captured into a hipGraph
- * (launch-bound consumers: tests/test_gpu_parity.py::test_launches_can_be_captured_into_a_hip_graph).  A captured
+ * A plan may be launched from several host threads and on any number of streams; launches on
+ * one stream run in order, launches on different streams may overlap (up to 64 long launches in flight at a time;
+ * a 65th waits for the oldest).  The calls leave the caller's current HIP device unchanged.
+ * The call enqueues one kernel; a long launch of the multi-wave sizes (4096 points and up, frames handed out by the
+ * ticket pools) additionally records an event behind it, by which its counter slot is recycled.  While the stream is
+ * being captured into a hipGraph nothing but the kernel is enqueued
+ * (launch-bound consumers: tests/test_gpu_parity.py::test_launches_can_be_captured_into_a_hip_graph); a captured
  * launch keeps the ticket-counter slot of the stream it was captured on: replay one instance of such a graph at a
  * time. */
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
@@ -167,8 +170,9 @@ int fsea_exec_f64_host(fsea_plan *plan, const double *iq, size_t n_frames, void 
  * shift = nrf_fft_shift's per-row scroll for an integer number of bins (src/nrf.c:569-596: > 0 moves
  * rows left, < 0 right, vacated bins zero, |shift| >= fft_size clears the history), as a kernel;
  * get = nrf_fft_get_buffer: ONE device-to-host transfer of rows * fft_size f32 and one widening to
- * f64 into `out` (rows * fft_size doubles).  The plan must be a MAG_F32 plan and must outlive the
- * history.  All calls are synchronous. */
+ * f64 into `out` (rows * fft_size doubles).  The plan must be a MAG_F32 plan and must outlive every
+ * push / shift / get on the history (destroy the history first; fsea_history_destroy itself no longer touches the
+ * plan).  All calls are synchronous. */
 int fsea_history_create(fsea_plan *plan, int rows, fsea_history **history);
 int fsea_history_destroy(fsea_history *history);
 int fsea_history_push_u8_host(fsea_history *history, const uint8_t *iq, int flip);

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Soak run: minutes of randomly drawn launches (size, mode, frame count, hop, byte convention, frame distribution,
-one of four streams, plain / tiled / frequency-shifted entry point), every one checked on sampled rows against numpy.
-Looks for what the unit tests cannot: rare interleavings of overlapping launches, ticket-counter residue, hangs.
-Usage: python scripts/soak.py [seconds, default 120] [seed]"""
+one of four streams, plain / tiled / frequency-shifted entry point), every one checked on sampled rows against numpy;
+in between, the synchronous host-memory entry points (u8, frequency-shifted, f64 input: the pipelined copy-in /
+transform / copy-out path) and the device-resident history ring (push, shift, get).
+Looks for what the unit tests cannot: rare interleavings of overlapping launches, ticket-counter residue, hangs, and the
+store-data hazard of the 16-byte row stores (a third of the launches are drawn from the sizes and modes that use them,
+long enough to load every CU, with more rows sampled).
+Usage: python scripts/soak.py [seconds, default 120] [seed | "random"]      (the seed is printed first)"""
 import ctypes
 import os
 import sys
@@ -15,7 +19,9 @@ sys.path.insert(0, ROOT)
 from frequensea_amd import fsea  # noqa: E402
 
 SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+SEED = 7 if len(sys.argv) <= 2 else (int.from_bytes(os.urandom(4), "little") if sys.argv[2] == "random" else int(sys.argv[2]))
+print("soak: seed %d" % SEED, flush=True)
+rng = np.random.default_rng(SEED)
 L = fsea.hip_lib()
 hip = ctypes.CDLL("libamdhip64.so")
 hip.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
@@ -67,6 +73,93 @@ def rows_numpy(offset_bytes, frame, n, hop, flip, mode, shift=None):
     return px
 
 
+def check_float(got, want, what, bound=5e-6):
+    rel = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+    assert rel < bound, (what, rel)
+
+
+host_calls = 0
+histories = {}
+
+
+def host_entry_points():
+    """One synchronous call of a host-memory entry point, or a few operations on a device-resident history ring, checked
+    at once: fsea_exec_u8_host (small = mapped staging, large = the pipelined path), _shifted_host, _f64_host;
+    fsea_history_push / shift / get against a numpy model of nrf_fft's history (src/nrf.c:569-631)."""
+    global host_calls
+    host_calls += 1
+    kind = int(rng.integers(4))
+    n = int(rng.choice(SIZES))
+    if kind == 3:
+        n = int(rng.choice([128, 1024, 4096]))
+        rows = 5
+        if n not in histories:
+            plan = fsea.Plan(n, mode=0)
+            h = ctypes.c_void_p()
+            fsea._check(L.fsea_history_create(plan._p, rows, ctypes.byref(h)))
+            histories[n] = (plan, h, np.zeros((rows, n)))
+        plan, h, model = histories[n]
+        for _ in range(int(rng.integers(1, 4))):
+            off = 16 * int(rng.integers(0, 4096))
+            fsea._check(L.fsea_history_push_u8_host(h, host[off:].ctypes.data, 1))
+            model[1:] = model[:-1].copy()
+            model[0] = rows_numpy(off, 0, n, n, True, 0)
+        if rng.random() < 0.5:
+            sh = int(rng.choice([-n, -7, -1, 1, 3, n // 2, n + 5]))
+            fsea._check(L.fsea_history_shift(h, sh))
+            new = np.zeros_like(model)
+            if 0 < sh < n:
+                new[:, : n - sh] = model[:, sh:]
+            elif -n < sh < 0:
+                new[:, -sh:] = model[:, : n + sh]
+            model[:] = new
+        got = np.empty((rows, n), np.float64)
+        fsea._check(L.fsea_history_get_f64(h, got.ctypes.data))
+        check_float(got, model, ("history", n))
+        return
+    mode = int(rng.choice([0, 0, 1, 3]))
+    hop = n if rng.random() < 0.7 else max(8, (n // 2) - (n // 2) % 8)
+    esz = {0: 4, 1: 1, 3: 8}[mode]
+    nf = int(rng.choice([1, 2, 5, 33, 700, 5000]))
+    nf = int(min(nf, (1 << 25) // (esz * n), ((1 << 24) - 2 * n) // (2 * hop) + 1))
+    flip = bool(rng.integers(2))
+    off = 16 * int(rng.integers(0, 2048))
+    key = (n, hop, mode)
+    if key not in plans:
+        plans[key] = fsea.Plan(n, hop=hop, mode=mode)
+    plan = plans[key]
+    raw = host[off: off + 2 * ((nf - 1) * hop + n)]
+    frames = sorted({0, nf - 1, int(rng.integers(nf))})
+    if kind == 0:
+        got = plan.exec_host(raw, nf, flip=flip)
+        shift = None
+    elif kind == 1:
+        shift = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0, 1)))
+        got = plan.exec_shifted_host(raw, nf, shift[0], shift[1], flip=flip)
+    else:                                          # f64 input: x[n] = (-1)^n (re + i im), no scaling, no flip
+        x = rng.normal(0, 0.3, 2 * ((nf - 1) * hop + n))
+        got = plan.exec_host_f64(x, nf)
+        for f in frames:
+            z = x[2 * f * hop: 2 * (f * hop + n)].reshape(n, 2)
+            X = np.fft.fft((z[:, 0] + 1j * z[:, 1]) * (1.0 - 2.0 * (np.arange(n) & 1)))
+            if mode == 0:
+                want = np.abs(X)
+                want[n // 2] = want[n // 2 - 1]
+            elif mode == 3:
+                want = X
+            else:
+                continue                           # (pixel rows of f64 input: covered by the unit tests)
+            check_float(got[f], want, ("f64 host", n, nf, hop, mode, f))
+        return
+    for f in frames:
+        want = rows_numpy(off, f, n, hop, flip, mode, shift)
+        if mode == 1:
+            delta = np.abs(got[f].astype(np.int32) - want.astype(np.int32))
+            assert delta.max() <= 1 and (delta != 0).sum() <= max(4, n // 50), ("host", kind, n, nf, hop, flip, f)
+        else:
+            check_float(got[f], want, ("host", kind, n, nf, hop, flip, mode, f))
+
+
 t_end = time.time() + SECONDS
 launches = checked = 0
 pending = [None] * len(streams)
@@ -76,7 +169,10 @@ while time.time() < t_end:
         assert hip.hipStreamSynchronize(streams[si]) == 0
         n, nf, hop, flip, mode, off, tiled, shape, shift = pending[si]
         dt = {0: np.float32, 1: np.uint8, 2: np.uint8, 3: np.complex64, 4: np.float32, 5: np.float32}[mode]
-        for f in sorted({0, nf - 1, int(rng.integers(nf))}):
+        # sizes / modes whose rows leave in 16-byte stores (four adjacent f32 bins or two complex bins per lane): sample more
+        wide = (mode in (0, 4, 5) and n in (64, 128, 2048)) or (mode == 3 and n in (32, 64, 128, 256, 512, 2048, 4096))
+        extra = [int(x) for x in rng.integers(0, nf, 12)] if wide else []
+        for f in sorted({0, nf - 1, int(rng.integers(nf))} | set(extra)):
             row = np.empty(n, dt)
             if tiled:
                 rows_t, stride, first_x, step = shape
@@ -104,13 +200,22 @@ while time.time() < t_end:
                     assert rel < 5e-6, (n, nf, hop, flip, mode, f, rel)
             checked += 1
         pending[si] = None
+    if rng.random() < 0.08:
+        host_entry_points()
+        continue
     n = int(rng.choice(SIZES))
     mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5]))
-    hop = n if rng.random() < 0.7 else int(rng.choice([n // 2, n // 4, 2 * n, 8]))
+    hazard_draw = rng.random() < 0.33
+    if hazard_draw:                                # the 16-byte-store kernels, long launches
+        n = int(rng.choice([64, 128, 2048]))
+        mode = int(rng.choice([0, 0, 3, 4, 5]))
+    hop = n if (hazard_draw or rng.random() < 0.7) else int(rng.choice([n // 2, n // 4, 2 * n, 8]))
     hop = max(8, hop - hop % 8)
     esz = {0: 4, 1: 1, 2: 1, 3: 8, 4: 4, 5: 4}[mode]
     nf_max = min((MAX_IN - 2 * n) // (2 * hop) + 1, (4 * MAX_IN) // (esz * n))
     nf = int(min(nf_max, rng.choice([1, 2, 3, 7, 64, 511, 4096, 20000, 70000])))
+    if hazard_draw:
+        nf = int(min(nf_max, max(nf, (1 << 23) // n)))
     flip = bool(rng.integers(2))
     off = 16 * int(rng.integers(0, 2048))
     key = (n, hop, mode)
@@ -139,5 +244,5 @@ while time.time() < t_end:
     launches += 1
 for s in streams:
     assert hip.hipStreamSynchronize(s) == 0
-print("soak: %.0f s, %d launches on %d streams, %d plans, %d rows checked against numpy, no mismatch, no hang"
-      % (SECONDS, launches, len(streams), len(plans), checked))
+print("soak: seed %d, %.0f s, %d launches on %d streams, %d host-memory / history calls, %d plans, %d rows checked against numpy, "
+      "no mismatch, no hang" % (SEED, SECONDS, launches, len(streams), host_calls, len(plans), checked))

@@ -371,6 +371,48 @@ def test_many_overlapping_launches_on_four_streams_and_reset(units_policy):
     plan.close()
 
 
+def test_a_plan_outlives_any_number_of_short_lived_streams():
+    """ticket-counter slots are recycled once the launch they served has completed, and launches that do not
+    use the counters (single-wave sizes, short launches) take none: a plan launched on far more than 64 distinct,
+    short-lived streams over its lifetime keeps working, with no device-wide synchronisation in between."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    for n, nf, policy in ((8192, 600, fsea.UNITS_TICKETS), (4096, 2100, fsea.UNITS_TICKETS), (1024, 300, fsea.UNITS_AUTO)):
+        plan = fsea.Plan(n)
+        plan.set_unit_distribution(policy)
+        iq = synth_iq(31 + n, 2 * nf * n)
+        want = O.rows(iq, 4, n)
+        want_last = O.rows(iq[2 * n * (nf - 2):], 2, n)
+        d_in = DeviceBuffer(iq.nbytes).upload(iq)
+        d_out = DeviceBuffer(nf * n * 4)
+        live = []
+        for k in range(150):
+            st = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+            plan.exec_device(d_in.ptr, nf, d_out.ptr, stream=st.value)
+            live.append(st)
+            if len(live) == 3:                     # a few streams alive at a time; handles get recycled by the runtime
+                old = live.pop(0)
+                assert hip.hipStreamSynchronize(old) == 0
+                hip.hipStreamDestroy(old)
+            if k % 37 == 0:
+                assert hip.hipStreamSynchronize(st) == 0
+                got = d_out.download(np.float32, (nf, n))
+                parity.check_float(got[:4], want)
+                parity.check_float(got[-2:], want_last)
+        for st in live:
+            assert hip.hipStreamSynchronize(st) == 0
+            hip.hipStreamDestroy(st)
+        got = d_out.download(np.float32, (nf, n))
+        parity.check_float(got[:4], want)
+        parity.check_float(got[-2:], want_last)
+        d_in.free()
+        d_out.free()
+        plan.close()
+
+
 def test_calls_leave_the_current_device_alone():
     """Every entry point runs on the plan's device and restores the caller's current HIP device
     (ADVICE r01); with one GPU the observable part is that it stays 0 and nothing fails."""

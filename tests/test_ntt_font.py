@@ -258,3 +258,34 @@ def test_damaged_font_files_are_refused_or_render_without_faults(tmp_path):
         L.ntt_font_draw(font, img.ctypes.data, 300, 80, b"0123456789.-", 150, 10, 48)
         L.ntt_font_free(font)
     assert loaded >= 1                        # damage outside the tables the labels use still loads
+
+
+@pytest.mark.parametrize("path", FONTS)
+@pytest.mark.parametrize("px", [48, 31])
+def test_measure_accumulates_kerning_like_the_reference_helper(path, px):
+    """c/fft-stitch.c:104-123: `int glyph_width = advance * font_scale; *width += glyph_width;` truncates the addend, but
+    `*width += font_scale * kern` on an int truncates the SUM (ADVICE r02).  The two differ for negative fractional kerns;
+    the expected widths are computed here with exactly that arithmetic from this library's own metrics (which are pinned
+    to the reference's stb_truetype in test_against_the_references_stb_truetype), on strings with kerned pairs."""
+    L = _lib()
+    font = L.ntt_font_load(path.encode())
+    assert font
+    scale = np.float32(L.ntt_font_scale_for_pixel_height(font, float(px)))
+    kerned = 0
+    for text in ("AV", "AVAVATo", "To.Wa,LT", "1802.5", "WAVE-11"):
+        width = 0
+        for i, ch in enumerate(text):
+            g = L.ntt_font_glyph_index(font, ord(ch))
+            adv, lsb = ctypes.c_int(), ctypes.c_int()
+            L.ntt_font_hmetrics(font, g, ctypes.byref(adv), ctypes.byref(lsb))
+            width += int(np.float32(adv.value) * scale)                       # truncated addend
+            if i + 1 < len(text):
+                k = L.ntt_font_kern_advance(font, g, L.ntt_font_glyph_index(font, ord(text[i + 1])))
+                kerned += k != 0
+                width = int(np.float32(width) + scale * np.float32(k))        # truncated sum
+        w, h = ctypes.c_int(), ctypes.c_int()
+        L.ntt_font_measure(font, text.encode(), 0, 0, px, ctypes.byref(w), ctypes.byref(h))
+        assert w.value == width, (text, w.value, width)
+    L.ntt_font_free(font)
+    if "DejaVuSans" in path and "Mono" not in path:
+        assert kerned > 0                                                     # DejaVu Sans kerns A-V, T-o, W-a
