@@ -1108,13 +1108,28 @@ int fsea_stream_synchronize(fsea_plan *p, void *stream) {
 // moves 16 bytes in and 32 bytes out per iteration.  What the memory system gives a kernel that does nothing else.
 typedef uint32_t tune_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void fsea_tune_stream_1to2_kernel(const tune_u32x4 *in, tune_u32x4 *out, size_t n16) {
+    // four independent 16-byte loads in flight per thread, every wave instruction 1 KiB contiguous in both directions
+    // (the two output halves are two contiguous streams, as the rows of two frames would be)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        tune_u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_nontemporal_load(in + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tune_u32x4 w = v[k];
+            w.x ^= 0x80808080u;
+            __builtin_nontemporal_store(v[k], out + i + k * stride);
+            __builtin_nontemporal_store(w, out + n16 + i + k * stride);
+        }
+    }
+    for (; i < n16; i += stride) {
         const tune_u32x4 v = __builtin_nontemporal_load(in + i);
         tune_u32x4 w = v;
         w.x ^= 0x80808080u;
-        __builtin_nontemporal_store(v, out + 2 * i);
-        __builtin_nontemporal_store(w, out + 2 * i + 1);
+        __builtin_nontemporal_store(v, out + i);
+        __builtin_nontemporal_store(w, out + n16 + i);
     }
 }
 
@@ -1130,7 +1145,8 @@ int fsea_tune_stream_1to2(void *const *d_in, void *const *d_out, int n_sets, siz
     hipEvent_t e0, e1;
     FSEA_HIP(hipEventCreate(&e0));
     FSEA_HIP(hipEventCreate(&e1));
-    const unsigned grid = (unsigned)prop.multiProcessorCount * 8u;
+    const char *wg_env = std::getenv("FSEA_TUNE_COPY_WG");  // workgroups per CU (default 32: two 16-byte pieces per thread; measured 0.58-0.67 of 8 TB/s at 2-16, 0.73 at 32)
+    const unsigned grid = (unsigned)prop.multiProcessorCount * (unsigned)(wg_env ? std::atoi(wg_env) : 32);
     FSEA_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < reps; ++i) {
         hipLaunchKernelGGL(fsea_tune_stream_1to2_kernel, dim3(grid), dim3(256), 0, s, static_cast<const tune_u32x4 *>(d_in[i % n_sets]),

@@ -28,7 +28,8 @@ def main():
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         fsea._check(L.fsea_device_alloc(0, in_bytes, ctypes.byref(a)))
         fsea._check(L.fsea_device_alloc(0, out_bytes, ctypes.byref(b)))
-        fsea._check(L.fsea_copy_to_device(0, a, np.roll(host, 16 * s).ctypes.data, in_bytes))
+        rolled = np.roll(host, 16 * s)                 # (kept alive across the call)
+        fsea._check(L.fsea_copy_to_device(0, a, rolled.ctypes.data, in_bytes))
         ins.append(a)
         outs.append(b)
     alg = in_bytes + out_bytes
