@@ -255,10 +255,12 @@ struct fsea_plan {
     } slots[FSEA_CTR_SLOTS];
     unsigned long long slot_seq = 0;
     unsigned long long *d_trace = nullptr;  // FSEA_TRACE diagnostics (tuning library)
-    int occ[fsea::K_COUNT] = {0, 0, 0, 0, 0, 0};
+    int occ[fsea::K_COUNT] = {};
     // FSEA_UNITS_AUTO: launches with at most FSEA_STATIC_UNITS_PER_WG units per workgroup use the static interleave,
     // longer ones the ticket pools; fsea_plan_set_unit_distribution pins one of the two
     int units_policy = FSEA_UNITS_AUTO;
+    int half_run_max = 8;          // frames per run of the half-overlap kernels at most (FSEA_HALF_RUN_MAX at plan creation; measured 4 .. 32)
+    bool no_half_overlap = false;  // FSEA_NO_HALF_OVERLAP=1 at plan creation: hop == N/2 runs the ordinary kernel (A/B measurements)
     // staging for the host-buffer entry points
     std::mutex mu;
     void *d_in = nullptr;
@@ -434,6 +436,24 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
         a.pitch_tile = tiles->pitch_tile;
         a.out_span = tiles->span;
     }
+    // 50 %-overlapped frames of the nrf_fft_process kind (raw int8, MAG rows) at the sizes with one frame per workgroup:
+    // the half-overlap kernel, runs of consecutive frames per workgroup (every sample loaded once), static units
+    if (kind == fsea::K_U8_MAG && e->launch_half && !tiles && 2 * (size_t)p->hop == (size_t)p->n && n_frames >= 2 &&
+        !p->no_half_overlap) {
+        const size_t wgs = (size_t)p->num_cu * (size_t)(p->occ[fsea::K_U8_MAG_HALF] > 0 ? p->occ[fsea::K_U8_MAG_HALF] : 1);
+        size_t run = n_frames / wgs;  // frames per run: long enough to reuse most halves, short enough that every workgroup gets some
+        if (run > (size_t)p->half_run_max) run = (size_t)p->half_run_max;
+        if (run < 1) run = 1;
+        a.run_len = (uint32_t)run;
+        a.dynamic_units = 0;
+        a.ctr = p->d_ctr;
+        const size_t units = (n_frames + run - 1) / run;
+        size_t g = wgs < units ? wgs : units;
+        if (g >= 8) g &= ~(size_t)7;
+        e->launch_half(a, (unsigned)g, s);
+        FSEA_HIP(hipGetLastError());
+        return FSEA_OK;
+    }
     // only a launch that hands its frames out by the ticket pools needs a counter slot (single-wave sizes and short
     // launches never touch the counters)
     int slot = -1;
@@ -507,10 +527,18 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     p->device = device;
     p->entry = e;
     p->num_cu = prop.multiProcessorCount;
+    p->no_half_overlap = std::getenv("FSEA_NO_HALF_OVERLAP") != nullptr;
+    if (const char *hr = std::getenv("FSEA_HALF_RUN_MAX")) {
+        const int v = std::atoi(hr);
+        if (v >= 1 && v <= 4096) p->half_run_max = v;
+    }
     {
         int k = pick_kind(fsea::IN_U8, mode, 1);  // the kernel raw int8 input (flip) launches
         if (!e->fn[k]) k = fsea::K_U8;
         p->kernel_name = e->name[k];
+        if (k == fsea::K_U8_MAG && e->launch_half && 2 * (size_t)hop == (size_t)fft_size && !p->no_half_overlap) {
+            p->kernel_name = e->name[fsea::K_U8_MAG_HALF];  // 50 %-overlapped frames run the half-overlap kernel
+        }
     }
 #ifdef FSEA_TUNE
     if (std::getenv("FSEA_TRACE")) {

@@ -333,6 +333,9 @@ struct FftArgs {
     size_t out_span = 0;
     // multi-wave sizes: 1 = units handed out by the ticket pools, 0 = static interleave (unit = blockIdx + k * grid)
     uint32_t dynamic_units = 1;
+    // half-overlap kernels (FftKernel<..., RUNS = true>, hop == N/2): a unit is a run of `run_len` consecutive frames, and
+    // inside a run the second half of a frame's bytes stays in registers as the first half of the next frame's
+    uint32_t run_len = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -551,9 +554,13 @@ __device__ __forceinline__ cf turn_phasor_f32(double turns) {
 // ROT: u8 input is multiplied by a running phasor before the transform (nrf_freq_shifter fused
 // into the load, src/nrf.c:843-866): x[n] = (-1)^n (u8/256) e^{2 pi i (phase0 + m delta)}, with
 // the shifter's + 0.5 (1+i) restored like the offset-binary DC, analytically in bin N/2.
-template <class Cfg, int IN, int MODE_T = -1, bool ROT = false>
+// RUNS: the 50 %-overlap form (hop == N/2, BASELINE.json's STFT configuration): a workgroup takes RUNS of consecutive
+// frames, and the second half of every frame's bytes -- pass-0 rows R0/2 .. R0-1 of each lane -- is kept in registers as
+// rows 0 .. R0/2-1 of the next frame, so that every sample is loaded once (FftArgs::run_len frames per run; static units).
+template <class Cfg, int IN, int MODE_T = -1, bool ROT = false, bool RUNS = false>
 struct FftKernel {
     static_assert(!ROT || IN == IN_U8, "the fused frequency shift is a u8-input path");
+    static_assert(!RUNS || (IN == IN_U8 && !ROT && Cfg::FPW == 1 && (Cfg::R(0) % 2) == 0), "half-overlap runs: u8 input, one frame per workgroup");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
     static constexpr int LAST = NP - 1;
     static constexpr int R0 = Cfg::R(0), C0 = Cfg::C(0);
@@ -643,11 +650,14 @@ struct FftKernel {
     static constexpr uint32_t IN_BPS = (IN == IN_U8) ? 2 : 8;  // input bytes per complex sample
 
     // voff: this lane's byte offset inside the unit's window (slot * hop + C0 t samples)
-    static __device__ __forceinline__ void load_raw(rsrc_t rs, uint32_t voff, Raw *raw) {
+    static __device__ __forceinline__ void load_raw(rsrc_t rs, uint32_t voff, Raw *raw) { load_raw_rows<0, R0>(rs, voff, raw); }
+
+    template <int RLO, int RHI>
+    static __device__ __forceinline__ void load_raw_rows(rsrc_t rs, uint32_t voff, Raw *raw) {
         constexpr int STRIDE = N / R0;
         // ABL 512 (measurement only, wrong samples per lane): the frame's bytes fetched 16 per lane, 1 KiB
         // runs per wave instruction -- what a pass-0 layout with 8 adjacent samples per lane would issue
-        if constexpr ((Cfg::ABL & 512) != 0 && IN == IN_U8 && C0 == 2 && R0 % 4 == 0 && FPW == 1) {
+        if constexpr ((Cfg::ABL & 512) != 0 && IN == IN_U8 && C0 == 2 && R0 % 4 == 0 && FPW == 1 && RLO == 0 && RHI == R0) {
 #pragma unroll
             for (int r = 0; r < R0 / 4; ++r) {
                 const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff * 4u, (uint32_t)(r * 16 * T), LD_AUX);
@@ -657,7 +667,7 @@ struct FftKernel {
             return;
         }
 #pragma unroll
-        for (int r = 0; r < R0; ++r) {
+        for (int r = RLO; r < RHI; ++r) {
             const uint32_t soff = (uint32_t)(r * STRIDE) * IN_BPS;
             if constexpr (IN == IN_U8) {
                 if constexpr (C0 == 1) raw[r].w = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, LD_AUX);
@@ -1458,7 +1468,7 @@ struct FftKernel {
 
         const unsigned b = blockIdx.x;
         const bool issuer = (tid == 0);
-        const size_t n_units = (a.n_frames + FPW - 1) / FPW;
+        const size_t n_units = RUNS ? (a.n_frames + a.run_len - 1) / a.run_len : (a.n_frames + FPW - 1) / FPW;
         Pools pools;
         pools.n_units = (unsigned)n_units;
         pools.grid = gridDim.x;
@@ -1500,7 +1510,10 @@ struct FftKernel {
         // The ticket pools pay for themselves when a workgroup gets many units (they even out the unequal progress of
         // workgroups and XCDs); with a handful each, the plain interleave is faster -- no atomics, no ticket word to wait
         // for, nothing to steal at the end (profiles/r02_static_vs_ticket_distribution.txt).  The host decides per launch.
-        const bool dyn = DYNAMIC && a.dynamic_units != 0;
+        const bool dyn = !RUNS && DYNAMIC && a.dynamic_units != 0;
+        // half-overlap runs: the frame this workgroup is on, and its place in the run
+        [[maybe_unused]] size_t fcur = RUNS ? (size_t)b * a.run_len : 0;
+        [[maybe_unused]] unsigned jpos = 0;
         if (dyn) {
             u = (size_t)pools.start(cur) + b / POOLS;         // static first unit
             if (u >= pools.start(cur + 1)) u = n_units;       // more workgroups than units in this pool
@@ -1524,7 +1537,7 @@ struct FftKernel {
             for (int c = 0; c < C1; ++c) ld_c<R1 / 2>(a.tw_def + ((C1 * t1 + c) % Ns1) * (R1 / 2), tw1 + c * (R1 / 2));
         }
         Raw raw[R0];
-        load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+        load_raw(buffer_window(a.in, (size_t)IN_BPS * (RUNS ? fcur : u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
         if (dyn) {
             if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
         }
@@ -1677,6 +1690,14 @@ struct FftKernel {
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
             size_t un = u + gridDim.x;
+            [[maybe_unused]] size_t fnext = 0;
+            [[maybe_unused]] bool same_run = false;
+            if constexpr (RUNS) {
+                static_assert(!RUNS || !TK_LATE, "half-overlap runs use the plain prefetch");
+                same_run = (jpos + 1 < a.run_len) && (fcur + 1 < a.n_frames);
+                un = same_run ? u : u + gridDim.x;
+                fnext = same_run ? fcur + 1 : un * (size_t)a.run_len;
+            }
             if constexpr (TK_LATE) {
                 // the ticket word is read in front of pass 1's data (LDS returns in order) and only
                 // waited for once those reads are in flight
@@ -1720,7 +1741,16 @@ struct FftKernel {
                         }
                     }
                 }
-                if constexpr ((Cfg::ABL & 64) == 0) {  // ABL 64 (measurement only): the first unit's bytes are reused
+                if constexpr (RUNS) {
+                    const rsrc_t rs = buffer_window(a.in, (size_t)IN_BPS * fnext * a.hop, un < n_units ? total_in : 0);
+                    if (same_run) {  // the bytes of rows R0/2 .. R0-1 are rows 0 .. R0/2-1 of the next frame: only its second half is fetched
+#pragma unroll
+                        for (int r = 0; r < R0 / 2; ++r) raw[r] = raw[r + R0 / 2];
+                        load_raw_rows<R0 / 2, R0>(rs, in_voff, raw);
+                    } else {
+                        load_raw(rs, in_voff, raw);
+                    }
+                } else if constexpr ((Cfg::ABL & 64) == 0) {  // ABL 64 (measurement only): the first unit's bytes are reused
                     load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
                 }
                 middle_pass<1>(lds, lds_all, v, a, t, tw1);
@@ -1753,8 +1783,12 @@ struct FftKernel {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0, MI>(v + c);
             }
-            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(u * FPW), total_out), out_elem, v, tl);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(RUNS ? fcur : u * FPW), total_out), out_elem, v, tl);
             u = un;
+            if constexpr (RUNS) {
+                fcur = fnext;
+                jpos = same_run ? jpos + 1 : 0;
+            }
             if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * b + 8 + iter] = wall_clock64();
             ++iter;
         }

@@ -14,7 +14,9 @@ namespace fsea {
 // DC fix, c/fft-batch-broad.c:106-121; DB10, c/fft-batch.c:83-94).  K_U8 takes any epilogue and
 // either byte convention at run time (uniform branch), K_U8_ROT adds the fused frequency shift,
 // K_F32 takes f32-complex input (the NUT_BUFFER_F64 branch).
-enum : int { K_U8_MAG = 0, K_U8_DB5 = 1, K_U8_DB10 = 2, K_U8 = 3, K_U8_ROT = 4, K_F32 = 5, K_COUNT = 6 };
+// K_U8_MAG_HALF: the MAG kernel for 50 %-overlapped frames (hop == N/2) of the sizes with one frame per workgroup (8192,
+// 16384): runs of consecutive frames per workgroup, every sample loaded once (FftKernel<..., RUNS = true>).
+enum : int { K_U8_MAG = 0, K_U8_DB5 = 1, K_U8_DB10 = 2, K_U8 = 3, K_U8_ROT = 4, K_F32 = 5, K_U8_MAG_HALF = 6, K_COUNT = 7 };
 
 struct KernelEntry {
     int n;                 // transform size
@@ -28,6 +30,7 @@ struct KernelEntry {
     const void *fn[K_COUNT];    // __global__ function addresses (occupancy queries); null = not compiled
     const char *name[K_COUNT];  // symbol names as rocprof shows them
     void (*launch)(int kind, const FftArgs &args, unsigned grid, hipStream_t stream);
+    void (*launch_half)(const FftArgs &args, unsigned grid, hipStream_t stream);  // K_U8_MAG_HALF, or null
 };
 
 // Each k_*.hip translation unit exports `int fsea_kernels_<tag>(KernelEntry *out, int cap)`
@@ -127,6 +130,21 @@ struct KernelEntry {
             {#NAME "_u8_mag", #NAME "_u8_db5", #NAME "_u8_db10", #NAME "_u8", "", ""},                \
             &NAME##_launch};                                                                          \
     }
+
+// The half-overlap MAG kernel of a configuration defined above (one frame per workgroup), and the entry that carries it.
+#define FSEA_DEFINE_HALF_OVERLAP(NAME)                                                                \
+    FSEA_KERNEL_FN_(NAME, _u8_mag_half, fsea::IN_U8, fsea::MODE_MAG, false, true)                     \
+    static void NAME##_launch_half(const fsea::FftArgs &a, unsigned grid, hipStream_t s) {            \
+        hipLaunchKernelGGL(NAME##_u8_mag_half, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a);            \
+    }                                                                                                 \
+    static fsea::KernelEntry NAME##_entry_half() {                                                    \
+        fsea::KernelEntry e = NAME##_entry();                                                         \
+        e.fn[fsea::K_U8_MAG_HALF] = reinterpret_cast<const void *>(&NAME##_u8_mag_half);              \
+        e.name[fsea::K_U8_MAG_HALF] = #NAME "_u8_mag_half";                                           \
+        e.launch_half = &NAME##_launch_half;                                                          \
+        return e;                                                                                     \
+    }
+#define FSEA_REGISTER_HALF(NAME) if (n < cap) out[n++] = NAME##_entry_half();
 
 #define FSEA_REGISTER_BEGIN(TAG)                                                                      \
     extern "C" int fsea_kernels_##TAG(fsea::KernelEntry *out, int cap) {                              \

@@ -2,6 +2,7 @@
 #include "fsea_configs.h"
 #include "fsea_registry.h"
 FSEA_DEFINE_KERNEL(fsea_fft8192, "", FSEA_CFG_8192)
+FSEA_DEFINE_HALF_OVERLAP(fsea_fft8192)
 FSEA_REGISTER_BEGIN(8192)
-FSEA_REGISTER(fsea_fft8192)
+FSEA_REGISTER_HALF(fsea_fft8192)
 FSEA_REGISTER_END

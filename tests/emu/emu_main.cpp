@@ -37,7 +37,7 @@ unsigned fsea::emu_lane_read(unsigned v, int src_lane) {
     return r;
 }
 
-template <class Cfg, int IN, int MODE_T, bool ROT = false>
+template <class Cfg, int IN, int MODE_T, bool ROT = false, bool RUNS = false>
 static void run_grid(fsea::FftArgs a, unsigned grid) {
     if (ROT) {
         fsea::TwPair rows[32];
@@ -84,7 +84,7 @@ static void run_grid(fsea::FftArgs a, unsigned grid) {
                 g_wave_barrier = wbar[t / 64].get();
                 g_wave_slot = &wslot[t / 64];
                 g_wave_lanes = &wlanes[(t / 64) * 64];
-                fsea::FftKernel<Cfg, IN, MODE_T, ROT>::run(a, lds);
+                fsea::FftKernel<Cfg, IN, MODE_T, ROT, RUNS>::run(a, lds);
             });
         }
         for (auto &x : th) x.join();
@@ -107,6 +107,10 @@ static int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsigned gr
         else if (mode_t == fsea::MODE_DB10_U8) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB10_U8>(a, grid);
         else run_grid<Cfg, fsea::IN_U8, -1>(a, grid);
         return 0;
+    } else
+    if (in_kind == 3) {  // the half-overlap MAG kernel (K_U8_MAG_HALF): hop == N/2, runs of g_run_len frames
+        if constexpr (Cfg::FPW == 1 && (Cfg::OPT & (64 | 512 | 1048576)) == 0) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, true>(a, grid);
+        else return -4;
     } else
     if (in_kind == fsea::IN_U8_ROT) run_grid<Cfg, fsea::IN_U8, -1, true>(a, grid);
     else if (in_kind == fsea::IN_U8 && mode_t == fsea::MODE_MAG) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG>(a, grid);
@@ -139,6 +143,10 @@ extern "C" void emu_set_shift(double cycles_per_sample, double phase0_cycles) {
 static uint32_t g_dynamic_units = 1;
 extern "C" void emu_set_dynamic_units(uint32_t on) { g_dynamic_units = on; }
 
+// half-overlap kernels (in_kind 3): frames per run
+static uint32_t g_run_len = 4;
+extern "C" void emu_set_run_len(uint32_t frames) { g_run_len = frames; }
+
 // tiled output (FftArgs::tile_rows ...): set before a call, cleared by it
 static uint32_t g_tile_rows = 0, g_pitch_row = 0, g_pitch_tile = 0;
 static size_t g_out_span = 0;
@@ -159,6 +167,10 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.pitch_tile = g_pitch_tile;
     a.out_span = g_out_span;
     a.dynamic_units = g_dynamic_units;
+    if (in_kind == 3) {
+        a.run_len = g_run_len;
+        a.dynamic_units = 0;
+    }
     g_tile_rows = 0;
     a.in = in;
     a.out = out;

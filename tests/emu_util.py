@@ -46,10 +46,14 @@ def emu_lib():
 
 
 def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0, variant="",
-             shift=None, dynamic_units=True):
+             shift=None, dynamic_units=True, run_len=None):
     """shift = (cycles_per_sample, phase0_cycles) selects the frequency-shifted u8 kernel (in_kind 2);
     dynamic_units=False runs the multi-wave sizes with the static unit interleave (FftArgs::dynamic_units = 0)."""
     hop = n if hop is None else hop
+    if run_len is not None:                      # the half-overlap MAG kernel (hop == n / 2), runs of run_len frames
+        in_kind = 3
+        emu_lib().emu_set_run_len.argtypes = [ctypes.c_uint32]
+        emu_lib().emu_set_run_len(int(run_len))
     emu_lib().emu_set_dynamic_units.argtypes = [ctypes.c_uint32]
     emu_lib().emu_set_dynamic_units(1 if dynamic_units else 0)
     if shift is not None:

@@ -243,3 +243,16 @@ def test_biased_pixel_rounding_equals_truncation_on_a_dense_sweep():
     assert np.all(np.abs(biased - trunc)[diff] == 1)
     frac = d[diff] - np.floor(d[diff])
     assert np.all(frac < 2e-5)
+
+
+@pytest.mark.parametrize("n,nf,grid,run_len", [(8192, 9, 2, 4), (8192, 5, 3, 1), (8192, 7, 2, 8), (16384, 6, 2, 3), (16384, 4, 1, 8)])
+def test_half_overlap_runs_keep_half_a_frame_in_registers(n, nf, grid, run_len):
+    """FftKernel<..., RUNS = true> (K_U8_MAG_HALF, hop == N/2): a workgroup takes runs of consecutive frames and keeps
+    pass-0 rows R0/2 .. R0-1 of a frame as rows 0 .. R0/2-1 of the next; ragged last runs, more workgroups than runs,
+    run length 1 (no reuse at all) -- the rows are those of the ordinary kernel, bit for bit."""
+    hop = n // 2
+    iq = synth_iq(n + nf + run_len, 2 * ((nf - 1) * hop + n))
+    got = emu_rows(iq, n, nf, hop=hop, grid=grid, run_len=run_len)
+    parity.check_mode(got, iq, n, nf, hop, True, 0)
+    plain = emu_rows(iq, n, nf, hop=hop, grid=grid, dynamic_units=False)
+    assert np.array_equal(got, plain)

@@ -413,6 +413,36 @@ def test_a_plan_outlives_any_number_of_short_lived_streams():
         plan.close()
 
 
+@pytest.mark.parametrize("n,nf", [(16384, 2000), (16384, 7), (8192, 4097), (8192, 2), (8192, 300)])
+def test_half_overlap_kernel_equals_the_ordinary_kernel(n, nf, monkeypatch):
+    """hop == N/2 with MAG rows of raw int8 input runs `*_u8_mag_half` at 8192 and 16384 points: runs of consecutive frames
+    per workgroup, the second half of each frame's bytes kept in registers for the next frame.  Same rows, bit for bit,
+    as the ordinary kernel (FSEA_NO_HALF_OVERLAP=1 at plan creation), and both against the oracle."""
+    hop = n // 2
+    iq = synth_iq(n + nf, 2 * ((nf - 1) * hop + n))
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    rows = {}
+    for half in (True, False):
+        if half:
+            monkeypatch.delenv("FSEA_NO_HALF_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("FSEA_NO_HALF_OVERLAP", "1")
+        plan = fsea.Plan(n, hop=hop)
+        assert plan.kernel_name == ("fsea_fft%d_u8_mag%s" % (n, "_half" if half else ""))
+        d_out = DeviceBuffer(nf * n * 4)
+        d_out.upload(np.full(nf * n, -1.0, np.float32))
+        plan.exec_device(d_in.ptr, nf, d_out.ptr)
+        plan.exec_device(d_in.ptr, nf, d_out.ptr)
+        plan.synchronize()
+        rows[half] = d_out.download(np.float32, (nf, n))
+        d_out.free()
+        plan.close()
+    assert np.array_equal(rows[True], rows[False])
+    for f in sorted({0, 1, nf // 2, nf - 1}):
+        parity.check_mode(rows[True][f:f + 1], iq[2 * f * hop:], n, 1, hop, True, 0)
+    d_in.free()
+
+
 def test_calls_leave_the_current_device_alone():
     """Every entry point runs on the plan's device and restores the caller's current HIP device
     (ADVICE r01); with one GPU the observable part is that it stays 0 and nothing fails."""

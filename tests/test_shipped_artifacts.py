@@ -62,11 +62,16 @@ def kernels():
 
 def test_every_size_has_its_six_entry_points_and_nothing_experimental(kernels):
     fft = sorted(k for k in kernels if k.startswith("fsea_fft"))
-    assert fft == sorted("fsea_fft%d_%s" % (n, kind) for n in SIZES for kind in KINDS)
+    # + the half-overlap MAG kernels of the two sizes with one frame per workgroup (hop == N/2: every sample loaded once)
+    assert fft == sorted(["fsea_fft%d_%s" % (n, kind) for n in SIZES for kind in KINDS] +
+                         ["fsea_fft8192_u8_mag_half", "fsea_fft16384_u8_mag_half"])
     assert not [k for k in kernels if "abl" in k]
 
 
 def test_hot_kernels_do_not_spill(kernels):
+    for name in ("fsea_fft8192_u8_mag_half", "fsea_fft16384_u8_mag_half"):
+        k = kernels[name]
+        assert k[".vgpr_count"] <= 256 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, name
     for n in SIZES:
         for kind in KINDS:
             k = kernels["fsea_fft%d_%s" % (n, kind)]
