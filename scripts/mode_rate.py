@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Steady-state rate of every epilogue mode (run-time-mode kernel `*_u8`, and the compile-time MAG
-kernel) on resident data.  Usage: python scripts/mode_rate.py [N ...]"""
+"""Steady-state rate of every epilogue mode (run-time-mode kernel `*_u8`, and the compile-time MAG / DB5 / DB10
+kernels) on resident data.  For the two u8 pixel modes the round-2 epilogue (cast + clamp + shift/or: tuning variant
+"px0") is timed alternately with the product kernel in the same process, so that the file shows what the
+v_cvt_pk_u8_f32 epilogue is worth on the box it was made on.  Usage: python scripts/mode_rate.py [N ...]"""
 import ctypes
 import os
 import sys
@@ -29,14 +31,25 @@ def main():
     for n in sizes:
         frames = TOTAL_SAMPLES // n
         for mode in range(6):
-            plan = fsea.Plan(n, mode=mode)
-            plan.time_device(d_in, frames, d_out, 20)
-            ms = sorted(plan.time_device(d_in, frames, d_out, 10) for _ in range(5))[2]
+            plans = [("", fsea.Plan(n, mode=mode))]
+            if mode in (1, 2):
+                try:
+                    plans.append(("px0", fsea.Plan(n, mode=mode, variant="px0")))
+                except fsea.FseaError:
+                    pass
+            times = {v: [] for v, _ in plans}
+            for _, plan in plans:
+                plan.time_device(d_in, frames, d_out, 20)
+            for rnd in range(5):
+                for v, plan in (plans if rnd % 2 == 0 else plans[::-1]):
+                    times[v].append(plan.time_device(d_in, frames, d_out, 10))
             bytes_ = frames * n * (2 + OUT_BYTES[mode])
-            print("N=%-6d %-13s %-24s %7.3f ms %8.1f Mframes/s %8.1f Gsamples/s %7.1f GB/s %5.1f%% of 8 TB/s" %
-                  (n, NAMES[mode], plan.kernel_name, ms, frames / ms / 1e3, frames * n / ms / 1e6,
-                   bytes_ / ms / 1e6, bytes_ / ms / 1e6 / 80))
-            plan.close()
+            for v, plan in plans:
+                ms = sorted(times[v])[2]
+                print("N=%-6d %-13s %-24s %7.3f ms %8.1f Mframes/s %8.1f Gsamples/s %7.1f GB/s %5.1f%% of 8 TB/s%s" %
+                      (n, NAMES[mode], plan.kernel_name, ms, frames / ms / 1e3, frames * n / ms / 1e6,
+                       bytes_ / ms / 1e6, bytes_ / ms / 1e6 / 80, "   (round-2 epilogue, same process)" if v else ""))
+                plan.close()
 
 
 if __name__ == "__main__":
