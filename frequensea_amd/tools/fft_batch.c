@@ -9,10 +9,12 @@
  * As in the reference one spectrum row is made from the first FFT_SIZE samples of each
  * transfer (c/fft-batch.c:62-69), the first 10 transfers after a retune are skipped
  * (:56-59, SAMPLE_BLOCKS_TO_SKIP) and the newest row is image row 0 (:72-74).
- * The per-sample loops and FFTW are one fused GPU launch per centre frequency (include/fsea.h).
+ * The per-sample loops and FFTW are one fused GPU launch per centre frequency (include/fsea.h), and the three host
+ * stages overlap (pipeline.h): capture k + 1 is being read and the PNG of capture k - 1 encoded while k is on the GPU.
  *
- * usage: fsea-fft-batch [--broad] [--rows H] [--fft N] [--skip K] [--out DIR] [--device D]
+ * usage: fsea-fft-batch [--broad] [--rows H] [--fft N] [--skip K] [--out DIR] [--device D] [--timing]
  *                       FREQ_MHZ=capture.raw [FREQ_MHZ=capture.raw ...]
+ *   --timing  print, at the end, the seconds each of the three stages was busy and the wall time of the loop
  */
 #include <math.h>
 #include <stdio.h>
@@ -21,6 +23,7 @@
 
 #include "easypng.h"
 #include "fsea.h"
+#include "pipeline.h"
 
 #define TRANSFER_BYTES 262144 /* one HackRF transfer: 131072 IQ samples */
 #define EVALUATE_ROWS 100     /* c/fft-batch-broad.c:22 */
@@ -30,8 +33,47 @@ static void die(const char *what) {
     exit(EXIT_FAILURE);
 }
 
+typedef struct {
+    char **args;          /* FREQ_MHZ=capture.raw, one per item */
+    int rows_wanted, skip;
+    size_t row_in;
+} batch_ctx;
+
+/* reader thread: rows of one capture, newest first: row y <- first 2N bytes of transfer skip + rows - 1 - y
+ * (c/fft-batch.c:62-74).  0 = loaded, > 0 = fatal (cannot open, short read), < 0 = too few transfers (skip it). */
+static int load_capture(void *vctx, int item, uint8_t *packed, int *rows_out) {
+    const batch_ctx *ctx = (const batch_ctx *)vctx;
+    const char *path = strchr(ctx->args[item], '=') + 1;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) {
+        fprintf(stderr, "fsea-fft-batch: cannot open %s\n", path);
+        return 1;
+    }
+    fseek(fp, 0L, SEEK_END);
+    const long transfers = ftell(fp) / TRANSFER_BYTES;
+    int rows = (int)(transfers - ctx->skip);
+    if (rows > ctx->rows_wanted) rows = ctx->rows_wanted;
+    if (rows <= 0) {
+        fprintf(stderr, "fsea-fft-batch: %s holds %ld transfers, need more than %d\n", path, transfers, ctx->skip);
+        fclose(fp);
+        return -1;
+    }
+    for (int y = 0; y < rows; y++) {
+        const long tr = (long)ctx->skip + rows - 1 - y;
+        fseek(fp, tr * (long)TRANSFER_BYTES, SEEK_SET);
+        if (fread(packed + (size_t)y * ctx->row_in, 1, ctx->row_in, fp) != ctx->row_in) {
+            fprintf(stderr, "Short read, samples lost, exiting!\n");
+            fclose(fp);
+            return 1;
+        }
+    }
+    fclose(fp);
+    *rows_out = rows;
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    int broad = 0, rows_wanted = -1, fft_size = -1, skip = 10, device = 0;
+    int broad = 0, rows_wanted = -1, fft_size = -1, skip = 10, device = 0, timing = 0;
     const char *out_dir = ".";
     int first_capture = argc;
     for (int i = 1; i < argc; i++) {
@@ -41,11 +83,12 @@ int main(int argc, char **argv) {
         else if (strcmp(argv[i], "--skip") == 0 && i + 1 < argc) skip = atoi(argv[++i]);
         else if (strcmp(argv[i], "--out") == 0 && i + 1 < argc) out_dir = argv[++i];
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = atoi(argv[++i]);
+        else if (strcmp(argv[i], "--timing") == 0) timing = 1;
         else { first_capture = i; break; }
     }
     if (first_capture >= argc) {
         fprintf(stderr, "usage: fsea-fft-batch [--broad] [--rows H] [--fft N] [--skip K] [--out DIR] "
-                        "[--device D] FREQ_MHZ=capture.raw ...\n");
+                        "[--device D] [--timing] FREQ_MHZ=capture.raw ...\n");
         return EXIT_FAILURE;
     }
     if (fft_size < 0) fft_size = broad ? 256 : 1024;          /* FFT_SIZE */
@@ -59,43 +102,42 @@ int main(int argc, char **argv) {
     void *d_iq = NULL, *d_px = NULL;
     if (fsea_device_alloc(device, (size_t)rows_wanted * row_in, &d_iq) != 0) die("fsea_device_alloc");
     if (fsea_device_alloc(device, (size_t)rows_wanted * (size_t)fft_size, &d_px) != 0) die("fsea_device_alloc");
-    uint8_t *packed = (uint8_t *)malloc((size_t)rows_wanted * row_in);
-    uint8_t *pixels = (uint8_t *)malloc((size_t)rows_wanted * (size_t)fft_size);
-
+    void *packed[2] = {NULL, NULL}, *pixels[2] = {NULL, NULL};
+    for (int k = 0; k < 2; k++) {
+        if (fsea_host_alloc((size_t)rows_wanted * row_in, &packed[k]) != 0) die("fsea_host_alloc");
+        if (fsea_host_alloc((size_t)rows_wanted * (size_t)fft_size, &pixels[k]) != 0) die("fsea_host_alloc");
+    }
     for (int i = first_capture; i < argc; i++) {
-        char *eq = strchr(argv[i], '=');
-        if (!eq) {
+        if (!strchr(argv[i], '=')) {
             fprintf(stderr, "fsea-fft-batch: expected FREQ_MHZ=capture.raw, got %s\n", argv[i]);
             return EXIT_FAILURE;
         }
-        const double freq_mhz = atof(argv[i]);
-        const char *path = eq + 1;
+    }
+    batch_ctx ctx = {argv + first_capture, rows_wanted, skip, row_in};
+    capture_reader reader;
+    png_writer writer;
+    if (capture_reader_start(&reader, argc - first_capture, load_capture, &ctx, (uint8_t *)packed[0], (uint8_t *)packed[1]) != 0 ||
+        png_writer_start(&writer, (uint8_t *)pixels[0], (uint8_t *)pixels[1]) != 0) {
+        fprintf(stderr, "fsea-fft-batch: cannot start the reader / writer threads\n");
+        return EXIT_FAILURE;
+    }
+
+    const double t_loop = stage_clock();
+    double gpu_s = 0.0;
+    for (int item = 0; item < argc - first_capture; item++) {
+        const double freq_mhz = atof(argv[first_capture + item]);
         printf("Frequency: %.4f MHz\n", freq_mhz);
-        FILE *fp = fopen(path, "rb");
-        if (!fp) {
-            fprintf(stderr, "fsea-fft-batch: cannot open %s\n", path);
-            return EXIT_FAILURE;
-        }
-        fseek(fp, 0L, SEEK_END);
-        const long transfers = ftell(fp) / TRANSFER_BYTES;
-        int rows = (int)(transfers - skip);
-        if (rows > rows_wanted) rows = rows_wanted;
-        if (rows <= 0) {
-            fprintf(stderr, "fsea-fft-batch: %s holds %ld transfers, need more than %d\n", path, transfers, skip);
-            fclose(fp);
+        uint8_t *iq = NULL;
+        int rows = 0;
+        const int rc = capture_reader_take(&reader, item, &iq, &rows);
+        if (rc > 0) return EXIT_FAILURE;      /* unreadable capture or short read: fatal, as in the reference */
+        if (rc < 0) {                          /* too few transfers: reported by the reader, next capture */
+            capture_reader_release(&reader, item);
             continue;
         }
-        /* row y (newest first) <- first 2N bytes of transfer skip + rows - 1 - y */
-        for (int y = 0; y < rows; y++) {
-            const long tr = (long)skip + rows - 1 - y;
-            fseek(fp, tr * (long)TRANSFER_BYTES, SEEK_SET);
-            if (fread(packed + (size_t)y * row_in, 1, row_in, fp) != row_in) {
-                fprintf(stderr, "Short read, samples lost, exiting!\n");
-                return EXIT_FAILURE;
-            }
-        }
-        fclose(fp);
-        if (fsea_copy_to_device(device, d_iq, packed, (size_t)rows * row_in) != 0) die("fsea_copy_to_device");
+        const double t_gpu = stage_clock();
+        if (fsea_copy_to_device(device, d_iq, iq, (size_t)rows * row_in) != 0) die("fsea_copy_to_device");
+        capture_reader_release(&reader, item); /* the reader may load capture item + 2 into this buffer */
 
         if (broad && rows >= EVALUATE_ROWS) {
             /* the first 100 rows received are the last 100 rows of the newest-first stack */
@@ -105,21 +147,37 @@ int main(int argc, char **argv) {
             printf("\n(Average power: %.2f)\n", avg);
             if (avg < 1.1) {
                 printf("Not interesting. Skipping...\n");
+                gpu_s += stage_clock() - t_gpu;
                 continue;
             }
         }
         if (fsea_exec_u8_device(plan, d_iq, (size_t)rows, 1, d_px, NULL) != 0) die("fsea_exec_u8_device");
-        if (fsea_copy_to_host(device, pixels, d_px, (size_t)rows * (size_t)fft_size) != 0) die("fsea_copy_to_host");
+        if (fsea_stream_synchronize(plan, NULL) != 0) die("fsea_stream_synchronize");
+        gpu_s += stage_clock() - t_gpu;
+        uint8_t *px = png_writer_acquire(&writer); /* waits for the PNG written from this buffer two captures ago */
+        const double t_down = stage_clock();
+        if (fsea_copy_to_host(device, px, d_px, (size_t)rows * (size_t)fft_size) != 0) die("fsea_copy_to_host");
+        gpu_s += stage_clock() - t_down;
         char file_name[512];
         if (broad) {
             snprintf(file_name, sizeof(file_name), "%s/broad-%.0f.png", out_dir, freq_mhz);
         } else {
             snprintf(file_name, sizeof(file_name), "%s/fft-%.4f.png", out_dir, freq_mhz);
         }
-        if (write_gray_png(file_name, fft_size, rows, pixels) != 0) return EXIT_FAILURE;
+        png_writer_submit(&writer, file_name, fft_size, rows);
     }
-    free(packed);
-    free(pixels);
+    capture_reader_join(&reader);
+    if (png_writer_finish(&writer) != 0) return EXIT_FAILURE;
+    if (timing) {
+        const double wall = stage_clock() - t_loop;
+        printf("Stages busy: read %.3f s, GPU (upload, gate, FFT, download) %.3f s, PNG %.3f s; wall %.3f s for %d captures "
+               "(one after the other: %.3f s)\n", reader.busy_s, gpu_s, writer.busy_s, wall, argc - first_capture,
+               reader.busy_s + gpu_s + writer.busy_s);
+    }
+    for (int k = 0; k < 2; k++) {
+        fsea_host_free(packed[k]);
+        fsea_host_free(pixels[k]);
+    }
     fsea_device_free(device, d_iq);
     fsea_device_free(device, d_px);
     fsea_plan_destroy(plan);

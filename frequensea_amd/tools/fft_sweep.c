@@ -10,7 +10,8 @@
  * rows, same gate), and the finished tiles travel chunk by chunk to member 0's GPU (fsea_comm_gather:
  * RCCL grouped send/recv over xGMI, include/fsea_comm.h), where they are max-composited into the stitched
  * image while the next chunk is being computed.  Tile PNGs are still written (by the member that made
- * them) unless --no-tiles.
+ * them) unless --no-tiles.  Every member overlaps its three host stages (pipeline.h): its next capture is being read
+ * and its previous tile's PNG encoded while the current one is on the GPU.
  *
  *   default   1024-pt, 16384 rows, *10 pixels, "fft-%.4f.png",  stitched "fft-stitched-%.4f-%.4f.png"
  *   --broad    256-pt,  4096 rows, *5 pixels + DC fix + 100-row gate, "broad-%.0f.png",
@@ -34,6 +35,7 @@
 #include "easypng.h"
 #include "fsea.h"
 #include "fsea_comm.h"
+#include "pipeline.h"
 
 #define TRANSFER_BYTES 262144 /* one HackRF transfer: 131072 IQ samples */
 #define EVALUATE_ROWS 100     /* c/fft-batch-broad.c:22 */
@@ -131,6 +133,16 @@ static int load_capture(const sweep_config *cfg, const capture *cap, uint8_t *pa
     return 0;
 }
 
+typedef struct {
+    const sweep_config *cfg;
+    int first; /* index of the member's first capture */
+} member_reader_ctx;
+
+static int member_loader(void *vctx, int item, uint8_t *packed, int *rows_out) {
+    const member_reader_ctx *c = (const member_reader_ctx *)vctx;
+    return load_capture(c->cfg, &c->cfg->captures[c->first + item], packed, rows_out);
+}
+
 static void *member_main(void *argp) {
     member_arg *arg = (member_arg *)argp;
     const sweep_config *cfg = arg->cfg;
@@ -141,15 +153,22 @@ static void *member_main(void *argp) {
 
     fsea_plan *plan = NULL;
     void *stream = NULL, *d_iq = NULL, *d_tiles = NULL, *d_inbox = NULL;
-    uint8_t *packed = (uint8_t *)malloc((size_t)rows * row_in);
-    uint8_t *pixels = (uint8_t *)malloc(tile_bytes);
+    void *packed[2] = {NULL, NULL}, *pixels[2] = {NULL, NULL};
+    for (int k = 0; k < 2; k++) {
+        CHECK(fsea_host_alloc((size_t)rows * row_in, &packed[k]) == 0 && fsea_host_alloc(tile_bytes, &pixels[k]) == 0,
+              "member %d: out of pinned host memory", me);
+    }
     int max_tiles = 0; /* largest per-member tile count: every member takes part in that many chunk gathers */
     for (int m = 0; m < cfg->n_members; m++) {
         const int cnt = cfg->hi[m] - cfg->lo[m];
         if (cnt > max_tiles) max_tiles = cnt;
     }
     const int depth = (max_tiles + cfg->chunk - 1) / cfg->chunk;
-    CHECK(packed && pixels, "member %d: out of memory", me);
+    member_reader_ctx rctx = {cfg, cfg->lo[me]};
+    capture_reader reader;
+    png_writer writer;
+    CHECK(capture_reader_start(&reader, mine, member_loader, &rctx, (uint8_t *)packed[0], (uint8_t *)packed[1]) == 0 &&
+          png_writer_start(&writer, (uint8_t *)pixels[0], (uint8_t *)pixels[1]) == 0, "member %d: reader / writer threads", me);
     CHECK(fsea_plan_create(&plan, n, n, cfg->broad ? FSEA_MODE_DB5_U8_DCFIX : FSEA_MODE_DB10_U8, device) == 0,
           "member %d: fsea_plan_create", me);
     CHECK(fsea_comm_stream_create(device, &stream) == 0, "member %d: stream", me);
@@ -168,11 +187,13 @@ static void *member_main(void *argp) {
             const capture *cap = &cfg->captures[cfg->lo[me] + k];
             char *tile = (char *)d_tiles + (size_t)k * tile_bytes;
             int got_rows = 0, keep = 1;
+            uint8_t *iq = NULL;
             printf("Frequency: %.4f MHz\n", cap->freq_mhz);
-            CHECK(load_capture(cfg, cap, packed, &got_rows) == 0, "member %d: %s", me, cap->path);
+            CHECK(capture_reader_take(&reader, k, &iq, &got_rows) == 0, "member %d: %s", me, cap->path);
             /* the stream may still read d_iq for the previous tile */
             CHECK(fsea_stream_synchronize(plan, stream) == 0, "member %d: sync", me);
-            CHECK(fsea_copy_to_device(device, d_iq, packed, (size_t)rows * row_in) == 0, "member %d: upload", me);
+            CHECK(fsea_copy_to_device(device, d_iq, iq, (size_t)rows * row_in) == 0, "member %d: upload", me);
+            capture_reader_release(&reader, k); /* the reader may load this member's capture k + 2 now */
             if (cfg->broad && rows >= EVALUATE_ROWS) {
                 /* the first 100 rows received are the last 100 rows of the newest-first stack (c/fft-batch-broad.c:81-98) */
                 double avg = 0.0;
@@ -187,16 +208,18 @@ static void *member_main(void *argp) {
             if (keep) {
                 CHECK(fsea_exec_u8_device(plan, d_iq, (size_t)rows, 1, tile, stream) == 0, "member %d: exec", me);
             } else {
-                memset(pixels, 0, tile_bytes); /* an all-zero tile changes nothing under max */
-                CHECK(fsea_copy_to_device(device, tile, pixels, tile_bytes) == 0, "member %d: clear", me);
+                uint8_t *zero = png_writer_acquire(&writer); /* (a free pixel buffer; nothing is submitted) */
+                memset(zero, 0, tile_bytes); /* an all-zero tile changes nothing under max */
+                CHECK(fsea_copy_to_device(device, tile, zero, tile_bytes) == 0, "member %d: clear", me);
             }
             if (keep && cfg->write_tiles) {
                 char file_name[600];
                 CHECK(fsea_stream_synchronize(plan, stream) == 0, "member %d: sync", me);
-                CHECK(fsea_copy_to_host(device, pixels, tile, tile_bytes) == 0, "member %d: download", me);
+                uint8_t *px = png_writer_acquire(&writer); /* waits for the PNG encoded from this buffer two tiles ago */
+                CHECK(fsea_copy_to_host(device, px, tile, tile_bytes) == 0, "member %d: download", me);
                 if (cfg->broad) snprintf(file_name, sizeof(file_name), "%s/broad-%.0f.png", cfg->out_dir, cap->freq_mhz);
                 else snprintf(file_name, sizeof(file_name), "%s/fft-%.4f.png", cfg->out_dir, cap->freq_mhz);
-                CHECK(write_gray_png(file_name, n, rows, pixels) == 0, "member %d: %s", me, file_name);
+                png_writer_submit(&writer, file_name, n, rows);
             }
         }
         /* gather chunk j: member m's tiles land at slot m of the root's inbox.  The inbox is reused per
@@ -227,8 +250,12 @@ static void *member_main(void *argp) {
     }
     /* all transfers complete, all source tiles free again */
     CHECK(fsea_comm_barrier(cfg->comm, me, stream) == 0, "member %d: barrier", me);
-    free(packed);
-    free(pixels);
+    capture_reader_join(&reader);
+    CHECK(png_writer_finish(&writer) == 0, "member %d: a tile PNG could not be written", me);
+    for (int k = 0; k < 2; k++) {
+        fsea_host_free(packed[k]);
+        fsea_host_free(pixels[k]);
+    }
     fsea_device_free(device, d_iq);
     fsea_device_free(device, d_tiles);
     fsea_device_free(device, d_inbox);
