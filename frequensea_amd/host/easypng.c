@@ -1,7 +1,8 @@
 /*
  * easypng.c -- 8-bit gray PNG writer / reader on zlib (include/easypng.h).
  * Writer: IHDR (8-bit, colour type 0, no interlace), one IDAT of the zlib-compressed
- * scanlines (filter type 0), IEND; what c/easypng.h:6-53 asks libpng for.
+ * scanlines (filter type 0), IEND; what c/easypng.h:6-53 asks libpng for.  Large images are
+ * deflated in up to eight slabs of rows on as many threads (one zlib stream, see deflate_slab).
  * Reader: all five scanline filters, colour types 0/2/4/6 at 8 bits, converted to gray with
  * stb_image's integer luma (77 r + 150 g + 29 b) >> 8, as c/fft-stitch.c:172 requests.
  */
@@ -36,6 +37,61 @@ static int write_chunk(FILE *fp, const char *type, const uint8_t *data, uint32_t
     return 0;
 }
 
+/* One slab of scanlines, compressed on its own thread as a raw deflate stream that ends on a byte boundary
+ * (Z_FULL_FLUSH; the last slab finishes the stream), so that the slabs' outputs concatenate into ONE valid deflate stream
+ * -- the way pigz writes.  A 1024 x 16384 tile (c/fft-batch.c's geometry) took 0.36 s to deflate on one core, a hundred
+ * times the GPU's share of that capture; eight slabs take it to a few tens of milliseconds. */
+typedef struct {
+    const uint8_t *pixels; /* first row of the slab */
+    int width, rows, last;
+    uint8_t *out;
+    size_t out_len, out_cap;
+    uLong adler; /* of the slab's raw bytes (filter bytes included) */
+    size_t raw_len;
+    int ok;
+} png_slab;
+
+static void *deflate_slab(void *p) {
+    png_slab *sl = (png_slab *)p;
+    const size_t stride = (size_t)sl->width + 1;
+    sl->raw_len = stride * (size_t)sl->rows;
+    sl->ok = 0;
+    uint8_t *raw = (uint8_t *)malloc(sl->raw_len);
+    sl->out_cap = compressBound((uLong)sl->raw_len) + 64;
+    sl->out = (uint8_t *)malloc(sl->out_cap);
+    if (!raw || !sl->out) {
+        free(raw);
+        return NULL;
+    }
+    for (int y = 0; y < sl->rows; y++) {
+        raw[(size_t)y * stride] = 0; /* filter type: none */
+        memcpy(raw + (size_t)y * stride + 1, sl->pixels + (size_t)y * (size_t)sl->width, (size_t)sl->width);
+    }
+    sl->adler = adler32(adler32(0L, Z_NULL, 0), raw, (uInt)sl->raw_len);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK) {
+        zs.next_in = raw;
+        zs.avail_in = (uInt)sl->raw_len;
+        zs.next_out = sl->out;
+        zs.avail_out = (uInt)sl->out_cap;
+        const int rc = deflate(&zs, sl->last ? Z_FINISH : Z_FULL_FLUSH);
+        if ((sl->last ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0) {
+            sl->out_len = sl->out_cap - zs.avail_out;
+            sl->ok = 1;
+        }
+        deflateEnd(&zs);
+    }
+    free(raw);
+    return NULL;
+}
+
+#include <pthread.h>
+#include <unistd.h>
+
+#define PNG_MAX_SLABS 8
+#define PNG_SLAB_MIN_BYTES ((size_t)1 << 18) /* bytes per slab at least: smaller images are one slab, compressed on the calling thread */
+
 int write_gray_png(const char *fname, int width, int height, const uint8_t *buffer) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (width <= 0 || height <= 0 || buffer == NULL) {
@@ -47,33 +103,64 @@ int write_gray_png(const char *fname, int width, int height, const uint8_t *buff
         printf("ERROR: Could not write open file %s for writing.\n", fname);
         return -1;
     }
-    const size_t stride = (size_t)width + 1;
-    uint8_t *raw = (uint8_t *)malloc(stride * (size_t)height);
-    uLongf zcap = compressBound((uLong)(stride * (size_t)height));
-    uint8_t *z = (uint8_t *)malloc(zcap);
+    const size_t stride = (size_t)width + 1, total = stride * (size_t)height;
+    long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+    int n_slabs = (int)(total / PNG_SLAB_MIN_BYTES);
+    if (n_slabs > PNG_MAX_SLABS) n_slabs = PNG_MAX_SLABS;
+    if (cpus > 0 && n_slabs > cpus) n_slabs = (int)cpus;
+    if (n_slabs > height) n_slabs = height;
+    if (n_slabs < 1) n_slabs = 1;
+    png_slab slabs[PNG_MAX_SLABS];
+    pthread_t threads[PNG_MAX_SLABS];
+    int started[PNG_MAX_SLABS];
+    const int per = (height + n_slabs - 1) / n_slabs;
+    n_slabs = (height + per - 1) / per;
+    for (int k = 0; k < n_slabs; k++) {
+        memset(&slabs[k], 0, sizeof(slabs[k]));
+        slabs[k].pixels = buffer + (size_t)k * (size_t)per * (size_t)width;
+        slabs[k].width = width;
+        slabs[k].rows = (k + 1) * per <= height ? per : height - k * per;
+        slabs[k].last = (k == n_slabs - 1);
+        started[k] = (k > 0) && pthread_create(&threads[k], NULL, deflate_slab, &slabs[k]) == 0;
+    }
+    deflate_slab(&slabs[0]);
+    for (int k = 1; k < n_slabs; k++) {
+        if (started[k]) pthread_join(threads[k], NULL);
+        else deflate_slab(&slabs[k]); /* no thread to be had: compress it here */
+    }
     int rc = -1;
-    if (raw && z) {
-        for (int y = 0; y < height; y++) {
-            raw[(size_t)y * stride] = 0; /* filter type: none */
-            memcpy(raw + (size_t)y * stride + 1, buffer + (size_t)y * (size_t)width, (size_t)width);
+    size_t zlen = 2 + 4;
+    int all_ok = 1;
+    for (int k = 0; k < n_slabs; k++) {
+        all_ok = all_ok && slabs[k].ok;
+        zlen += slabs[k].out_len;
+    }
+    uint8_t *z = all_ok && zlen <= 0x7fffffffu ? (uint8_t *)malloc(zlen) : NULL;
+    if (z) {
+        size_t pos = 2;
+        uLong adler = adler32(0L, Z_NULL, 0);
+        z[0] = 0x78; /* deflate, 32 KiB window */
+        z[1] = 0x9c; /* default compression, no dictionary; (0x789c % 31 == 0) */
+        for (int k = 0; k < n_slabs; k++) {
+            memcpy(z + pos, slabs[k].out, slabs[k].out_len);
+            pos += slabs[k].out_len;
+            adler = (k == 0) ? slabs[k].adler : adler32_combine(adler, slabs[k].adler, (z_off_t)slabs[k].raw_len);
         }
-        if (compress2(z, &zcap, raw, (uLong)(stride * (size_t)height), Z_DEFAULT_COMPRESSION) == Z_OK &&
-            zcap <= 0x7fffffffu) {
-            uint8_t ihdr[13];
-            put_u32(ihdr, (uint32_t)width);
-            put_u32(ihdr + 4, (uint32_t)height);
-            ihdr[8] = 8;  /* bit depth */
-            ihdr[9] = 0;  /* gray */
-            ihdr[10] = 0; /* deflate */
-            ihdr[11] = 0; /* adaptive filtering */
-            ihdr[12] = 0; /* no interlace */
-            if (fwrite(sig, 1, 8, fp) == 8 && write_chunk(fp, "IHDR", ihdr, 13) == 0 &&
-                write_chunk(fp, "IDAT", z, (uint32_t)zcap) == 0 && write_chunk(fp, "IEND", NULL, 0) == 0) {
-                rc = 0;
-            }
+        put_u32(z + pos, (uint32_t)adler);
+        uint8_t ihdr[13];
+        put_u32(ihdr, (uint32_t)width);
+        put_u32(ihdr + 4, (uint32_t)height);
+        ihdr[8] = 8;  /* bit depth */
+        ihdr[9] = 0;  /* gray */
+        ihdr[10] = 0; /* deflate */
+        ihdr[11] = 0; /* adaptive filtering */
+        ihdr[12] = 0; /* no interlace */
+        if (fwrite(sig, 1, 8, fp) == 8 && write_chunk(fp, "IHDR", ihdr, 13) == 0 &&
+            write_chunk(fp, "IDAT", z, (uint32_t)zlen) == 0 && write_chunk(fp, "IEND", NULL, 0) == 0) {
+            rc = 0;
         }
     }
-    free(raw);
+    for (int k = 0; k < n_slabs; k++) free(slabs[k].out);
     free(z);
     if (fclose(fp) != 0) rc = -1;
     if (rc == 0) {

@@ -213,6 +213,41 @@ def test_replay_device_missing_file_is_zero_block():
         L.nrf_device_free(dev)
 
 
+def test_png_writer_deflates_large_images_in_slabs(tmp_path):
+    """Images of a MiB and more are deflated as up to eight slabs of rows on as many threads, concatenated into one zlib
+    stream (host/easypng.c): ragged slab heights, compressible and incompressible content; decoded by PIL, by this
+    library's reader and by zlib itself (one stream, correct Adler-32)."""
+    import struct
+    import zlib
+    from PIL import Image
+    L = ctypes.CDLL(nrf.lib_path())
+    L.write_gray_png.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.read_gray_png.restype = ctypes.POINTER(ctypes.c_uint8)
+    L.read_gray_png.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(5)
+    for shape, kind in (((4099, 1024), "noise"), ((1031, 2048), "smooth"), ((8192, 256), "noise"), ((3, 700000), "smooth")):
+        if kind == "noise":
+            img = rng.integers(0, 256, shape, dtype=np.uint8)
+        else:
+            img = ((np.arange(shape[0])[:, None] // 7 + np.arange(shape[1])[None, :] // 5) % 251).astype(np.uint8)
+        path = str(tmp_path / "big.png")
+        assert L.write_gray_png(path.encode(), shape[1], shape[0], np.ascontiguousarray(img).ctypes.data) == 0
+        with Image.open(path) as im:
+            assert im.mode == "L" and np.array_equal(np.array(im), img)
+        w, h = ctypes.c_int(), ctypes.c_int()
+        p = L.read_gray_png(path.encode(), ctypes.byref(w), ctypes.byref(h))
+        assert (h.value, w.value) == shape and np.array_equal(np.ctypeslib.as_array(p, shape=shape), img)
+        data = open(path, "rb").read()
+        pos, idat = 8, b""
+        while pos < len(data):
+            ln, typ = struct.unpack(">I4s", data[pos:pos + 8])
+            if typ == b"IDAT":
+                idat += data[pos + 8: pos + 8 + ln]
+            pos += 12 + ln
+        raw = zlib.decompress(idat)                      # checks the combined Adler-32 too
+        assert len(raw) == shape[0] * (shape[1] + 1)
+
+
 def test_png_writer_and_reader_against_pil(tmp_path):
     """include/easypng.h: same on-disk format as the reference's libpng writer (8-bit gray,
     non-interlaced); checked both ways against an independent codec (PIL)."""
