@@ -229,6 +229,87 @@ __global__ void fsea_f64_to_f32_kernel(const double *in, float *out, size_t n) {
     }
 }
 
+
+// ---- Bluestein's algorithm: the transform sizes FFTW takes and the power-of-two kernels do not (src/nrf.c:564) ----
+// X[k] = conj(w[k]) * sum_j (x[j] conj(w[j])) w[k - j],  w[j] = e^{i pi j^2 / n}: a length-n DFT as a circular convolution
+// of length m = 2^p >= 2n - 1, i.e. two forward transforms of the power-of-two kernels (IN_F32 -> COMPLEX_F32) around a
+// pointwise product with the precomputed spectrum of the chirp.  The inner kernels apply the reference's (-1)^j centring
+// themselves (they are the NUT_BUFFER_F64 branch of nrf_fft_process): in front of the first transform that IS the
+// centring of x; in front of the second it is cancelled by a (-1)^k in the pointwise kernel.
+// u8 input is transformed as (u - 128) / 256 and the spectrum of the constant 0.5 (1 + i) -- one bin for even n, spread
+// over all bins for odd n -- is added from a table computed in double (blu_dc), as the power-of-two kernels restore
+// bin n/2 analytically: the large offset never passes through f32 arithmetic.
+__global__ void fsea_blu_prep_kernel(const void *in, int in_f32, uint32_t xormask, size_t hop, int n, int m, const fsea::cf *chirp_conj,
+                                     fsea::cf *a, size_t n_frames) {
+    const size_t total = n_frames * (size_t)m;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / (size_t)m;
+        const int j = (int)(i - f * (size_t)m);
+        fsea::cf v = fsea::cf{0.0f, 0.0f};
+        if (j < n) {
+            float re, im;
+            if (in_f32) {
+                const float *src = static_cast<const float *>(in) + 2 * (f * hop + (size_t)j);
+                re = src[0];
+                im = src[1];
+            } else {
+                const uint8_t *src = static_cast<const uint8_t *>(in) + 2 * (f * hop + (size_t)j);
+                const uint8_t mask = (uint8_t)xormask;  // 0: raw int8 (flip), 0x80: offset binary
+                re = (float)(int8_t)(src[0] ^ mask) * (1.0f / 256.0f);
+                im = (float)(int8_t)(src[1] ^ mask) * (1.0f / 256.0f);
+            }
+            const fsea::cf w = chirp_conj[j];
+            v = fsea::cf{re * w[0] - im * w[1], re * w[1] + im * w[0]};
+        }
+        a[i] = v;
+    }
+}
+
+// d[k] = (-1)^k conj(A[k] B[k])
+__global__ void fsea_blu_mul_kernel(const fsea::cf *A, const fsea::cf *B, fsea::cf *d, int m, size_t n_frames) {
+    const size_t total = n_frames * (size_t)m;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % (size_t)m);
+        const fsea::cf x = A[i], b = B[k];
+        const float re = x[0] * b[0] - x[1] * b[1], im = x[0] * b[1] + x[1] * b[0];
+        const float sgn = (k & 1) ? -1.0f : 1.0f;
+        d[i] = fsea::cf{sgn * re, -sgn * im};
+    }
+}
+
+// X[k] = conj(w[k]) conj(E[k]) / m (+ dc[k]), then the plan's epilogue; one thread per output bin
+__global__ void fsea_blu_epilogue_kernel(const fsea::cf *E, const fsea::cf *chirp_conj, const fsea::cf *dc, int n, int m, int mode,
+                                         void *out, size_t n_frames) {
+    const size_t total = n_frames * (size_t)n;
+    const float inv_m = 1.0f / (float)m;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / (size_t)n;
+        int k = (int)(i - f * (size_t)n);
+        const bool patched = (mode == FSEA_MODE_MAG_F32 || mode == FSEA_MODE_DB5_U8_DCFIX);
+        if (patched && k == n / 2 && k > 0) k -= 1;  // bin n/2 := bin n/2 - 1 (src/nrf.c:626-628; c/fft-batch-broad.c:115-117)
+        const fsea::cf e = E[f * (size_t)m + (size_t)k], w = chirp_conj[k];
+        // conj(w_k) conj(e) = conj(w_k e)... with chirp_conj = conj(w): X = chirp_conj[k] * conj(e)
+        float re = (w[0] * e[0] + w[1] * e[1]) * inv_m, im = (w[1] * e[0] - w[0] * e[1]) * inv_m;
+        if (dc) {
+            re += dc[k][0];
+            im += dc[k][1];
+        }
+        const float p = re * re + im * im;
+        if (mode == FSEA_MODE_COMPLEX_F32) {
+            static_cast<fsea::cf *>(out)[i] = fsea::cf{re, im};
+        } else if (mode == FSEA_MODE_DB10_U8 || mode == FSEA_MODE_DB5_U8_DCFIX) {
+            const float d = 10.0f * log10f(p + 1.0e-20f) * (mode == FSEA_MODE_DB10_U8 ? 10.0f : 5.0f);
+            int q = (int)d;
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            static_cast<uint8_t *>(out)[i] = (uint8_t)q;
+        } else if (mode == FSEA_MODE_DB_F32) {
+            static_cast<float *>(out)[i] = 10.0f * log10f(p + 1.0e-20f);
+        } else {
+            static_cast<float *>(out)[i] = sqrtf(p);
+        }
+    }
+}
+
 }  // namespace
 
 struct fsea_plan {
@@ -279,6 +360,15 @@ struct fsea_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // the pipelined host-buffer path (exec_host_pipelined): copy-in and copy-out streams beside `stream`, and one
     // "chunk arrived" / "chunk transformed" event pair per chunk in flight
+    // Bluestein plans (transform sizes without a kernel of their own): `n` is the logical size, `entry` the power-of-two
+    // kernel set of size blu_m the convolution runs on
+    int blu_m = 0;
+    fsea_plan *blu_inner = nullptr;          // size blu_m, COMPLEX_F32
+    fsea::cf *d_blu_chirp = nullptr;         // conj(w[j]), j < n
+    fsea::cf *d_blu_bfft = nullptr;          // FFT_m of the wrapped chirp
+    fsea::cf *d_blu_dc = nullptr;            // spectrum of the offset-binary DC term, n entries
+    fsea::cf *d_blu_work[2] = {nullptr, nullptr};
+    size_t blu_work_frames = 0;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_in[FSEA_HOST_CHUNKS_MAX] = {}, ev_done[FSEA_HOST_CHUNKS_MAX] = {};
     std::string kernel_name;
@@ -394,8 +484,25 @@ struct TileLayout {
     size_t span = 0;
 };
 
+int blu_launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out, hipStream_t s);
+
+int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
+                hipStream_t s, double rot_delta, double rot_phase0, const TileLayout *tiles);
+
 int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
            hipStream_t s, double rot_delta = 0.0, double rot_phase0 = 0.0, const TileLayout *tiles = nullptr) {
+    if (p->blu_m) {
+        if (in_kind == fsea::IN_U8_ROT || tiles) {
+            return fail(FSEA_EINVAL, "fft_size %d runs through Bluestein's algorithm: the frequency-shifted and the tiled "
+                                     "entry points exist for the power-of-two sizes only", p->n);
+        }
+        return blu_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s);
+    }
+    return launch_pow2(p, in_kind, d_in, n_frames, flip, mode, d_out, s, rot_delta, rot_phase0, tiles);
+}
+
+int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
+                hipStream_t s, double rot_delta, double rot_phase0, const TileLayout *tiles) {
     if (n_frames == 0) return FSEA_OK;
     int kind = pick_kind(in_kind, mode, flip);
     const fsea::KernelEntry *e = p->entry;
@@ -473,6 +580,72 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
     return FSEA_OK;
 }
 
+// One Bluestein pass over n_frames frames (in chunks that fit the work buffers): prep -> FFT_m -> x chirp spectrum -> FFT_m ->
+// epilogue, all on stream `s`.  d_in: u8 IQ or f32 complex (device, or device-mapped host memory), frame f at sample f * hop.
+int blu_launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out, hipStream_t s) {
+    if (n_frames == 0) return FSEA_OK;
+    const int n = p->n, m = p->blu_m;
+    const size_t esz = mode_elem_bytes(mode);
+    const size_t in_bps = (in_kind == fsea::IN_F32) ? 8 : 2;
+    for (size_t f0 = 0; f0 < n_frames; f0 += p->blu_work_frames) {
+        const size_t nf = (n_frames - f0 < p->blu_work_frames) ? n_frames - f0 : p->blu_work_frames;
+        const size_t total = nf * (size_t)m;
+        unsigned blocks = (unsigned)((total + 255) / 256);
+        if (blocks > 8192) blocks = 8192;
+        const char *src = static_cast<const char *>(d_in) + f0 * (size_t)p->hop * in_bps;
+        hipLaunchKernelGGL(fsea_blu_prep_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const void *>(src),
+                           in_kind == fsea::IN_F32 ? 1 : 0, flip ? 0u : 0x80u, (size_t)p->hop, n, m, p->d_blu_chirp, p->d_blu_work[0], nf);
+        int rc = launch_pow2(p->blu_inner, fsea::IN_F32, p->d_blu_work[0], nf, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s, 0.0, 0.0, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fsea_blu_mul_kernel, dim3(blocks), dim3(256), 0, s, p->d_blu_work[1], p->d_blu_bfft, p->d_blu_work[0], m, nf);
+        rc = launch_pow2(p->blu_inner, fsea::IN_F32, p->d_blu_work[0], nf, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s, 0.0, 0.0, nullptr);
+        if (rc) return rc;
+        unsigned eblocks = (unsigned)((nf * (size_t)n + 255) / 256);
+        if (eblocks > 8192) eblocks = 8192;
+        hipLaunchKernelGGL(fsea_blu_epilogue_kernel, dim3(eblocks), dim3(256), 0, s, p->d_blu_work[1], p->d_blu_chirp,
+                           in_kind == fsea::IN_F32 ? nullptr : p->d_blu_dc, n, m, mode,
+                           static_cast<void *>(static_cast<char *>(d_out) + f0 * (size_t)n * esz), nf);
+        FSEA_HIP(hipGetLastError());
+    }
+    return FSEA_OK;
+}
+
+// host-side double FFT (radix 2, in place) for the chirp's spectrum: plan creation only
+void host_fft(std::vector<double> &re, std::vector<double> &im) {
+    const size_t m = re.size();
+    for (size_t i = 1, j = 0; i < m; ++i) {
+        size_t bit = m >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    for (size_t len = 2; len <= m; len <<= 1) {
+        const double ang = -6.283185307179586476925286766559 / (double)len;
+        for (size_t i = 0; i < m; i += len) {
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(ang * (double)k), wi = std::sin(ang * (double)k);
+                const size_t a = i + k, b = i + k + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr;
+                im[b] = im[a] - ti;
+                re[a] += tr;
+                im[a] += ti;
+            }
+        }
+    }
+}
+
+// sizes without a kernel of their own that Bluestein's algorithm covers: 2 <= n <= 8192 (m = 2^p >= 2n - 1 <= 16384)
+int bluestein_m(int n) {
+    if (n < 2 || n > 8192) return 0;
+    int m = 32;
+    while (m < 2 * n - 1) m <<= 1;
+    return m <= 16384 ? m : 0;
+}
+
 int check_exec_args(const fsea_plan *plan, const void *in, const void *out, size_t align) {
     if (!plan) return fail(FSEA_EINVAL, "plan is NULL");
     if (!in || !out) return fail(FSEA_EINVAL, "NULL buffer");
@@ -495,19 +668,79 @@ int fsea_device_count(int *count) {
     return FSEA_OK;
 }
 
+// tables and work buffers of a Bluestein plan (p->n, p->blu_m set, device current)
+static int blu_setup(fsea_plan *p) {
+    const int n = p->n, m = p->blu_m;
+    const double pi = 3.14159265358979323846264338327950288;
+    std::vector<fsea::TwPair> chirp((size_t)n), dc((size_t)n), bf((size_t)m);
+    std::vector<double> br((size_t)m, 0.0), bi((size_t)m, 0.0);
+    for (int j = 0; j < n; ++j) {
+        const long long q = ((long long)j * (long long)j) % (2LL * n);  // j^2 mod 2n: the phase, reduced exactly
+        const double ang = pi * (double)q / (double)n;
+        const double wr = std::cos(ang), wi = std::sin(ang);
+        chirp[(size_t)j] = fsea::TwPair{(float)wr, (float)-wi};          // conj(w[j])
+        br[(size_t)j] = wr;
+        bi[(size_t)j] = wi;
+        if (j) {
+            br[(size_t)(m - j)] = wr;
+            bi[(size_t)(m - j)] = wi;
+        }
+    }
+    host_fft(br, bi);
+    for (int k = 0; k < m; ++k) bf[(size_t)k] = fsea::TwPair{(float)br[(size_t)k], (float)bi[(size_t)k]};
+    // spectrum of the offset-binary DC term 0.5 (1 + i) (-1)^j: n at bin n/2 for even n, 2 / (1 - r_k) for odd n,
+    // r_k = e^{i (pi - 2 pi k / n)}
+    for (int k = 0; k < n; ++k) {
+        double sr = 0.0, si = 0.0;
+        if ((n & 1) == 0) {
+            if (k == n / 2) sr = (double)n;
+        } else {
+            const double ang = pi - 2.0 * pi * (double)k / (double)n;
+            const double dr = 1.0 - std::cos(ang), di = -std::sin(ang);     // 1 - r
+            const double den = dr * dr + di * di;
+            sr = 2.0 * dr / den;
+            si = -2.0 * di / den;
+        }
+        dc[(size_t)k] = fsea::TwPair{(float)(0.5 * (sr - si)), (float)(0.5 * (sr + si))};  // 0.5 (1 + i) S
+    }
+    // work buffers: about 64 MiB each, at least one frame
+    size_t frames = ((size_t)64 << 20) / ((size_t)m * sizeof(fsea::cf));
+    if (frames < 1) frames = 1;
+    if (frames > 65536) frames = 65536;
+    p->blu_work_frames = frames;
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_blu_chirp), (size_t)n * sizeof(fsea::cf)));
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_blu_dc), (size_t)n * sizeof(fsea::cf)));
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_blu_bfft), (size_t)m * sizeof(fsea::cf)));
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_blu_work[0]), frames * (size_t)m * sizeof(fsea::cf)));
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_blu_work[1]), frames * (size_t)m * sizeof(fsea::cf)));
+    FSEA_HIP(hipMemcpy(p->d_blu_chirp, chirp.data(), (size_t)n * sizeof(fsea::cf), hipMemcpyHostToDevice));
+    FSEA_HIP(hipMemcpy(p->d_blu_dc, dc.data(), (size_t)n * sizeof(fsea::cf), hipMemcpyHostToDevice));
+    FSEA_HIP(hipMemcpy(p->d_blu_bfft, bf.data(), (size_t)m * sizeof(fsea::cf), hipMemcpyHostToDevice));
+    return FSEA_OK;
+}
+
 static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int device, const char *variant) {
     if (!out) return fail(FSEA_EINVAL, "plan out-pointer is NULL");
     *out = nullptr;
     if (mode < FSEA_MODE_MAG_F32 || mode > FSEA_MODE_DB_F32) return fail(FSEA_EINVAL, "unknown mode %d", mode);
     const fsea::KernelEntry *e = find_entry(fft_size, variant);
+    int blu_m = 0;
     if (!e) {
         if (variant && variant[0]) {
             return fail(FSEA_EINVAL, "no kernel variant '%s' for fft_size %d", variant, fft_size);
         }
-        return fail(FSEA_EINVAL, "unsupported fft_size %d: the gfx950 kernels cover powers of two in [32, 16384] "
-                                 "(FFTW's other sizes have no kernel here)", fft_size);
+        // a size FFTW takes and no kernel has: Bluestein's algorithm on the power-of-two kernels of size m >= 2n - 1
+        blu_m = bluestein_m(fft_size);
+        if (blu_m) e = find_entry(blu_m, "");
+        if (!e) {
+            return fail(FSEA_EINVAL, "unsupported fft_size %d: the gfx950 kernels cover powers of two in [32, 16384] directly and "
+                                     "every size in [2, 8192] through Bluestein's algorithm (FFTW's larger sizes have no kernel here)",
+                        fft_size);
+        }
     }
-    if (hop <= 0 || (hop % 8) != 0) return fail(FSEA_EINVAL, "hop must be a positive multiple of 8 (got %d)", hop);
+    if (hop <= 0 || (!blu_m && (hop % 8) != 0)) {
+        return fail(FSEA_EINVAL, "hop must be a positive multiple of 8 (any positive hop for the Bluestein sizes); got %d", hop);
+    }
     int count = 0;
     hipError_t ce = hipGetDeviceCount(&count);
     if (ce != hipSuccess || count <= 0) {
@@ -526,6 +759,7 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     p->mode = mode;
     p->device = device;
     p->entry = e;
+    p->blu_m = blu_m;
     p->num_cu = prop.multiProcessorCount;
     p->no_half_overlap = std::getenv("FSEA_NO_HALF_OVERLAP") != nullptr;
     if (const char *hr = std::getenv("FSEA_HALF_RUN_MAX")) {
@@ -583,6 +817,15 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
         fsea_plan_destroy(p);
         return rc;
     }
+    if (blu_m) {
+        int rc = create_plan(&p->blu_inner, blu_m, blu_m, FSEA_MODE_COMPLEX_F32, device, "");
+        if (rc == FSEA_OK) rc = blu_setup(p);
+        if (rc != FSEA_OK) {
+            fsea_plan_destroy(p);
+            return rc;
+        }
+        p->kernel_name = std::string("bluestein(") + p->blu_inner->entry->name[fsea::K_F32] + " x2)";
+    }
     *out = p;
     return FSEA_OK;
 }
@@ -610,6 +853,12 @@ int fsea_plan_destroy(fsea_plan *p) {
     if (!p) return FSEA_OK;
     DeviceGuard device_guard_(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->blu_inner) (void)fsea_plan_destroy(p->blu_inner);
+    if (p->d_blu_chirp) (void)hipFree(p->d_blu_chirp);
+    if (p->d_blu_dc) (void)hipFree(p->d_blu_dc);
+    if (p->d_blu_bfft) (void)hipFree(p->d_blu_bfft);
+    if (p->d_blu_work[0]) (void)hipFree(p->d_blu_work[0]);
+    if (p->d_blu_work[1]) (void)hipFree(p->d_blu_work[1]);
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);

@@ -624,6 +624,90 @@ def test_nrf_fft_lua_sizes_and_f64_input(golden, history_mode):
         L.nrf_fft_free(fft)
 
 
+def _expected_rows_any_size(iq, n, nf, hop, flip, mode, exact):
+    """Rows for a transform size the oracle's power-of-two FFT does not take: the oracle's own loops around its O(n^2)
+    long-double DFT (`exact`, small n) or around numpy's f64 FFT (large n: an O(n^2) check there would take minutes)."""
+    rows = []
+    for f in range(nf):
+        raw = iq[2 * f * hop: 2 * (f * hop + n)]
+        x = O.unpack_center_u8(O.flip_u8(raw) if flip else raw)
+        spec = O.dft_naive(x) if exact else np.fft.fft(x)
+        rows.append({0: lambda: O.mag_row(spec), 1: lambda: O.db_u8_row(spec, 10.0, 0), 2: lambda: O.db_u8_row(spec, 5.0, 1),
+                     3: lambda: spec, 4: lambda: np.abs(spec)}[mode]())
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("n", [1000, 1001, 96, 17, 16, 2, 3000, 8191])
+def test_transform_sizes_fftw_takes_and_the_kernels_do_not(n):
+    """`fftw_plan_dft_1d` (src/nrf.c:564) takes any size; the gfx950 kernels are powers of two from 32 to 16384.  Every
+    other size from 2 to 8192 runs through Bluestein's algorithm on those kernels (two transforms of size 2^p >= 2n - 1
+    around a pointwise product with the chirp's spectrum; the offset-binary DC term restored from a table, for odd n in
+    every bin).  Same tolerance as the power-of-two sizes; bin n/2 := bin n/2 - 1 with the integer n/2 of the reference."""
+    nf, exact = 3, n <= 1001
+    for hop in (n, max(1, n // 3)):
+        iq = synth_iq(n + hop, 2 * ((nf - 1) * hop + n))
+        for mode in (0, 3, 1, 2, 4):
+            for flip in ((True, False) if mode in (0, 1) else (True,)):
+                plan = fsea.Plan(n, hop=hop, mode=mode)
+                assert plan.kernel_name.startswith("bluestein(fsea_fft")
+                got = plan.exec_host(iq, nf, flip=flip)
+                plan.close()
+                want = _expected_rows_any_size(iq, n, nf, hop, flip, mode, exact)
+                if mode in (1, 2):
+                    parity.check_u8(got, want)
+                else:
+                    parity.check_float(got, want)
+                if mode in (0, 2) and n >= 4:
+                    assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
+    # resident data, a batch larger than the work buffers' chunk, f64 input, and the entry points that do not exist
+    nf = 70000 if n == 17 else 9
+    iq = synth_iq(5 * n, 2 * nf * n)
+    plan = fsea.Plan(n)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_out = DeviceBuffer(nf * n * 4)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    got = d_out.download(np.float32, (nf, n))
+    for f in (0, nf // 2, nf - 1):
+        parity.check_float(got[f:f + 1], _expected_rows_any_size(iq[2 * f * n:], n, 1, n, True, 0, exact))
+    x = np.random.default_rng(n).normal(0, 0.3, 2 * 2 * n)
+    got = plan.exec_host_f64(x, 2)
+    for f in range(2):
+        spec = np.fft.fft(O.unpack_center_f64(x[2 * f * n: 2 * (f + 1) * n]))
+        parity.check_float(got[f], O.mag_row(spec))
+    with pytest.raises(fsea.FseaError, match="Bluestein"):
+        plan.exec_shifted_device(d_in.ptr, 1, d_out.ptr, 0.01)
+    d_in.free()
+    d_out.free()
+    plan.close()
+
+
+def test_nrf_fft_with_a_size_that_is_not_a_power_of_two(history_mode):
+    """nrf_fft_new(1000, 4) as a Lua script could ask for (FFTW plans any size): process / get_buffer / shift through the
+    reference's API, both history modes."""
+    L = nrf.nrf_lib()
+    n, h = 1000, 4
+    fft = L.nrf_fft_new(n, h)
+    raws = [synth_iq(40 + k, nrf.NRF_BUFFER_SIZE_BYTES) ^ np.uint8(0x80) for k in range(3)]   # device buffers are offset binary
+    for raw in raws:
+        buf = _nut_u8(L, raw)
+        L.nrf_fft_process(fft, buf)
+        L.nut_buffer_free(buf)
+    out = L.nrf_fft_get_buffer(fft)
+    hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+    L.nut_buffer_free(out)
+    want = np.stack([O.mag_row(O.dft_naive(O.unpack_center_u8(raw[: 2 * n]))) for raw in reversed(raws)])
+    parity.check_float(hist[:3], want)
+    assert not hist[3].any()
+    ref = hist.copy()
+    O.fft_shift(ref, n, h, 7.0)
+    L.nrf_fft_shift(fft, 7.0)
+    out = L.nrf_fft_get_buffer(fft)
+    assert np.array_equal(nrf.buffer_to_numpy(L, out).reshape(h, n), ref)
+    L.nut_buffer_free(out)
+    L.nrf_fft_free(fft)
+
+
 def test_block_graph_device_to_fft(tmp_path):
     """nrf_block_connect(device, fft): the replay thread pushes rows (src/nrf.c:37-50,118)."""
     import time
