@@ -310,6 +310,78 @@ __global__ void fsea_blu_epilogue_kernel(const fsea::cf *E, const fsea::cf *chir
     }
 }
 
+// ---- four-step transform: powers of two above 16384 (fftw_plan_dft_1d takes them) on two passes of the kernels ----
+// n = N1 N2; sample j = N2 j1 + j2, bin k = k1 + N1 k2:
+//   X[k1 + N1 k2] = sum_{j2} W_N2^{j2 k2} ( W_n^{j2 k1} sum_{j1} x[N2 j1 + j2] W_N1^{j1 k1} )
+// i.e. N2 transforms of size N1 over the columns, a twiddle, N1 transforms of size N2, and two transposes folded into the
+// helper kernels.  Same conventions as the Bluestein path: the inner kernels' own (-1)^j centring is compensated, u8 input
+// is transformed as (u - 128) / 256 and the offset-binary DC term (bin n/2: n is even) is added at the end.
+__global__ void fsea_fs_prep_kernel(const void *in, int in_f32, uint32_t xormask, size_t hop, int n1, int n2, fsea::cf *a, size_t n_frames) {
+    const size_t n = (size_t)n1 * (size_t)n2, total = n_frames * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / n, r = i - f * n;
+        const size_t j2 = r / (size_t)n1, j1 = r - j2 * (size_t)n1;   // a[f][j2][j1]
+        const size_t j = (size_t)n2 * j1 + j2;
+        float re, im;
+        if (in_f32) {
+            const float *src = static_cast<const float *>(in) + 2 * (f * hop + j);
+            re = src[0];
+            im = src[1];
+        } else {
+            const uint8_t *src = static_cast<const uint8_t *>(in) + 2 * (f * hop + j);
+            const uint8_t mask = (uint8_t)xormask;
+            re = (float)(int8_t)(src[0] ^ mask) * (1.0f / 256.0f);
+            im = (float)(int8_t)(src[1] ^ mask) * (1.0f / 256.0f);
+        }
+        // the reference's (-1)^j (j and j2 have the same parity: N2 is even) and the inner kernel's own (-1)^{j1}, undone
+        const float sgn = ((j2 ^ j1) & 1) ? -1.0f : 1.0f;
+        a[i] = fsea::cf{sgn * re, sgn * im};
+    }
+}
+
+// b[f][k1][j2] = A[f][j2][k1] W_n^{j2 k1} (-1)^{j2}
+__global__ void fsea_fs_twiddle_kernel(const fsea::cf *A, const fsea::cf *tw, fsea::cf *b, int n1, int n2, size_t n_frames) {
+    const size_t n = (size_t)n1 * (size_t)n2, total = n_frames * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / n, r = i - f * n;
+        const size_t k1 = r / (size_t)n2, j2 = r - k1 * (size_t)n2;   // b[f][k1][j2]
+        const fsea::cf x = A[f * n + j2 * (size_t)n1 + k1], w = tw[j2 * (size_t)n1 + k1];
+        const float sgn = (j2 & 1) ? -1.0f : 1.0f;
+        b[i] = fsea::cf{sgn * (x[0] * w[0] - x[1] * w[1]), sgn * (x[0] * w[1] + x[1] * w[0])};
+    }
+}
+
+// out[f][k1 + N1 k2] = B[f][k1][k2] (+ DC at bin n/2), then the plan's epilogue
+__global__ void fsea_fs_epilogue_kernel(const fsea::cf *B, int add_dc, int n1, int n2, int mode, void *out, size_t n_frames) {
+    const size_t n = (size_t)n1 * (size_t)n2, total = n_frames * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / n;
+        size_t k = i - f * n;
+        const bool patched = (mode == FSEA_MODE_MAG_F32 || mode == FSEA_MODE_DB5_U8_DCFIX);
+        if (patched && k == n / 2) k -= 1;
+        const size_t k2 = k / (size_t)n1, k1 = k - k2 * (size_t)n1;
+        const fsea::cf e = B[f * n + k1 * (size_t)n2 + k2];
+        float re = e[0], im = e[1];
+        if (add_dc && k == n / 2) {
+            re += 0.5f * (float)n;
+            im += 0.5f * (float)n;
+        }
+        const float p = re * re + im * im;
+        if (mode == FSEA_MODE_COMPLEX_F32) {
+            static_cast<fsea::cf *>(out)[i] = fsea::cf{re, im};
+        } else if (mode == FSEA_MODE_DB10_U8 || mode == FSEA_MODE_DB5_U8_DCFIX) {
+            const float d = 10.0f * log10f(p + 1.0e-20f) * (mode == FSEA_MODE_DB10_U8 ? 10.0f : 5.0f);
+            int q = (int)d;
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            static_cast<uint8_t *>(out)[i] = (uint8_t)q;
+        } else if (mode == FSEA_MODE_DB_F32) {
+            static_cast<float *>(out)[i] = 10.0f * log10f(p + 1.0e-20f);
+        } else {
+            static_cast<float *>(out)[i] = sqrtf(p);
+        }
+    }
+}
+
 }  // namespace
 
 struct fsea_plan {
@@ -369,6 +441,10 @@ struct fsea_plan {
     fsea::cf *d_blu_dc = nullptr;            // spectrum of the offset-binary DC term, n entries
     fsea::cf *d_blu_work[2] = {nullptr, nullptr};
     size_t blu_work_frames = 0;
+    // four-step plans (powers of two above 16384): n = fs_n1 * fs_n2, two inner plans, the twiddles W_n^{j2 k1}
+    int fs_n1 = 0, fs_n2 = 0;
+    fsea_plan *fs_inner1 = nullptr, *fs_inner2 = nullptr;
+    fsea::cf *d_fs_tw = nullptr;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_in[FSEA_HOST_CHUNKS_MAX] = {}, ev_done[FSEA_HOST_CHUNKS_MAX] = {};
     std::string kernel_name;
@@ -485,18 +561,21 @@ struct TileLayout {
 };
 
 int blu_launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out, hipStream_t s);
+int fs_launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out, hipStream_t s);
 
 int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
                 hipStream_t s, double rot_delta, double rot_phase0, const TileLayout *tiles);
 
 int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out,
            hipStream_t s, double rot_delta = 0.0, double rot_phase0 = 0.0, const TileLayout *tiles = nullptr) {
-    if (p->blu_m) {
+    if (p->blu_m || p->fs_n1) {
         if (in_kind == fsea::IN_U8_ROT || tiles) {
-            return fail(FSEA_EINVAL, "fft_size %d runs through Bluestein's algorithm: the frequency-shifted and the tiled "
-                                     "entry points exist for the power-of-two sizes only", p->n);
+            return fail(FSEA_EINVAL, "fft_size %d runs through %s: the frequency-shifted and the tiled "
+                                     "entry points exist for the power-of-two sizes from 32 to 16384 only", p->n,
+                        p->blu_m ? "Bluestein's algorithm" : "the four-step decomposition");
         }
-        return blu_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s);
+        return p->blu_m ? blu_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s)
+                        : fs_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s);
     }
     return launch_pow2(p, in_kind, d_in, n_frames, flip, mode, d_out, s, rot_delta, rot_phase0, tiles);
 }
@@ -595,16 +674,41 @@ int blu_launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int
         const char *src = static_cast<const char *>(d_in) + f0 * (size_t)p->hop * in_bps;
         hipLaunchKernelGGL(fsea_blu_prep_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const void *>(src),
                            in_kind == fsea::IN_F32 ? 1 : 0, flip ? 0u : 0x80u, (size_t)p->hop, n, m, p->d_blu_chirp, p->d_blu_work[0], nf);
-        int rc = launch_pow2(p->blu_inner, fsea::IN_F32, p->d_blu_work[0], nf, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s, 0.0, 0.0, nullptr);
+        int rc = launch(p->blu_inner, fsea::IN_F32, p->d_blu_work[0], nf, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s);
         if (rc) return rc;
         hipLaunchKernelGGL(fsea_blu_mul_kernel, dim3(blocks), dim3(256), 0, s, p->d_blu_work[1], p->d_blu_bfft, p->d_blu_work[0], m, nf);
-        rc = launch_pow2(p->blu_inner, fsea::IN_F32, p->d_blu_work[0], nf, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s, 0.0, 0.0, nullptr);
+        rc = launch(p->blu_inner, fsea::IN_F32, p->d_blu_work[0], nf, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s);
         if (rc) return rc;
         unsigned eblocks = (unsigned)((nf * (size_t)n + 255) / 256);
         if (eblocks > 8192) eblocks = 8192;
         hipLaunchKernelGGL(fsea_blu_epilogue_kernel, dim3(eblocks), dim3(256), 0, s, p->d_blu_work[1], p->d_blu_chirp,
                            in_kind == fsea::IN_F32 ? nullptr : p->d_blu_dc, n, m, mode,
                            static_cast<void *>(static_cast<char *>(d_out) + f0 * (size_t)n * esz), nf);
+        FSEA_HIP(hipGetLastError());
+    }
+    return FSEA_OK;
+}
+
+// One four-step pass over n_frames frames (in chunks that fit the work buffers, shared with the Bluestein fields).
+int fs_launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int flip, int mode, void *d_out, hipStream_t s) {
+    if (n_frames == 0) return FSEA_OK;
+    const int n1 = p->fs_n1, n2 = p->fs_n2;
+    const size_t n = (size_t)p->n, esz = mode_elem_bytes(mode);
+    const size_t in_bps = (in_kind == fsea::IN_F32) ? 8 : 2;
+    for (size_t f0 = 0; f0 < n_frames; f0 += p->blu_work_frames) {
+        const size_t nf = (n_frames - f0 < p->blu_work_frames) ? n_frames - f0 : p->blu_work_frames;
+        unsigned blocks = (unsigned)((nf * n + 255) / 256);
+        if (blocks > 16384) blocks = 16384;
+        const char *src = static_cast<const char *>(d_in) + f0 * (size_t)p->hop * in_bps;
+        hipLaunchKernelGGL(fsea_fs_prep_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const void *>(src),
+                           in_kind == fsea::IN_F32 ? 1 : 0, flip ? 0u : 0x80u, (size_t)p->hop, n1, n2, p->d_blu_work[0], nf);
+        int rc = launch(p->fs_inner1, fsea::IN_F32, p->d_blu_work[0], nf * (size_t)n2, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fsea_fs_twiddle_kernel, dim3(blocks), dim3(256), 0, s, p->d_blu_work[1], p->d_fs_tw, p->d_blu_work[0], n1, n2, nf);
+        rc = launch(p->fs_inner2, fsea::IN_F32, p->d_blu_work[0], nf * (size_t)n1, 0, FSEA_MODE_COMPLEX_F32, p->d_blu_work[1], s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fsea_fs_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p->d_blu_work[1], in_kind == fsea::IN_F32 ? 0 : 1, n1, n2,
+                           mode, static_cast<void *>(static_cast<char *>(d_out) + f0 * n * esz), nf);
         FSEA_HIP(hipGetLastError());
     }
     return FSEA_OK;
@@ -638,12 +742,26 @@ void host_fft(std::vector<double> &re, std::vector<double> &im) {
     }
 }
 
-// sizes without a kernel of their own that Bluestein's algorithm covers: 2 <= n <= 8192 (m = 2^p >= 2n - 1 <= 16384)
+#define FSEA_MAX_FFT_SIZE (1 << 20)  // largest transform: four-step up to 2^20 points; Bluestein's m = 2^p >= 2n - 1 within it
+
+// powers of two above 16384 up to FSEA_MAX_FFT_SIZE: n = n1 * n2, both kernel sizes; n1 >= n2
+bool fourstep_split(int n, int *n1, int *n2) {
+    if (n <= 16384 || n > FSEA_MAX_FFT_SIZE || (n & (n - 1)) != 0) return false;
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    *n1 = 1 << ((lg + 1) / 2);
+    *n2 = n / *n1;
+    return *n1 <= 16384 && *n2 >= 32;
+}
+
+// sizes without a kernel of their own that Bluestein's algorithm covers: m = 2^p >= 2n - 1, itself a kernel size or a
+// four-step size (everything that is not a power of two, and the powers of two below 32)
 int bluestein_m(int n) {
-    if (n < 2 || n > 8192) return 0;
+    if (n < 2 || 2LL * n - 1 > FSEA_MAX_FFT_SIZE) return 0;
+    if ((n & (n - 1)) == 0 && n >= 32) return 0;
     int m = 32;
     while (m < 2 * n - 1) m <<= 1;
-    return m <= 16384 ? m : 0;
+    return m;
 }
 
 int check_exec_args(const fsea_plan *plan, const void *in, const void *out, size_t align) {
@@ -665,6 +783,27 @@ int fsea_device_count(int *count) {
     hipError_t e = hipGetDeviceCount(&n);
     if (count) *count = (e == hipSuccess) ? n : 0;
     if (e != hipSuccess || n <= 0) return fail(FSEA_ENODEVICE, "no HIP device: %s", hipGetErrorString(e));
+    return FSEA_OK;
+}
+
+// twiddles W_n^{j2 k1} and work buffers of a four-step plan (p->n = fs_n1 * fs_n2)
+static int fs_setup(fsea_plan *p) {
+    const size_t n = (size_t)p->n, n1 = (size_t)p->fs_n1, n2 = (size_t)p->fs_n2;
+    std::vector<fsea::TwPair> tw(n);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (size_t j2 = 0; j2 < n2; ++j2) {
+        for (size_t k1 = 0; k1 < n1; ++k1) {
+            const double ang = -two_pi * (double)((j2 * k1) % n) / (double)n;   // reduced exactly
+            tw[j2 * n1 + k1] = fsea::TwPair{(float)std::cos(ang), (float)std::sin(ang)};
+        }
+    }
+    size_t frames = ((size_t)64 << 20) / (n * sizeof(fsea::cf));
+    if (frames < 1) frames = 1;
+    p->blu_work_frames = frames;
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_fs_tw), n * sizeof(fsea::cf)));
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_blu_work[0]), frames * n * sizeof(fsea::cf)));
+    FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_blu_work[1]), frames * n * sizeof(fsea::cf)));
+    FSEA_HIP(hipMemcpy(p->d_fs_tw, tw.data(), n * sizeof(fsea::cf), hipMemcpyHostToDevice));
     return FSEA_OK;
 }
 
@@ -724,22 +863,28 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     *out = nullptr;
     if (mode < FSEA_MODE_MAG_F32 || mode > FSEA_MODE_DB_F32) return fail(FSEA_EINVAL, "unknown mode %d", mode);
     const fsea::KernelEntry *e = find_entry(fft_size, variant);
-    int blu_m = 0;
+    int blu_m = 0, fs_n1 = 0, fs_n2 = 0;
     if (!e) {
         if (variant && variant[0]) {
             return fail(FSEA_EINVAL, "no kernel variant '%s' for fft_size %d", variant, fft_size);
         }
-        // a size FFTW takes and no kernel has: Bluestein's algorithm on the power-of-two kernels of size m >= 2n - 1
-        blu_m = bluestein_m(fft_size);
-        if (blu_m) e = find_entry(blu_m, "");
+        // a size FFTW takes and no kernel has: a power of two above 16384 in two passes of the kernels (four-step), anything
+        // else by Bluestein's algorithm on a power of two m >= 2n - 1
+        if (fourstep_split(fft_size, &fs_n1, &fs_n2)) {
+            e = find_entry(fs_n1, "");
+        } else {
+            blu_m = bluestein_m(fft_size);
+            if (blu_m) e = find_entry(blu_m <= 16384 ? blu_m : 16384, "");
+        }
         if (!e) {
-            return fail(FSEA_EINVAL, "unsupported fft_size %d: the gfx950 kernels cover powers of two in [32, 16384] directly and "
-                                     "every size in [2, 8192] through Bluestein's algorithm (FFTW's larger sizes have no kernel here)",
-                        fft_size);
+            return fail(FSEA_EINVAL, "unsupported fft_size %d: the gfx950 kernels cover powers of two in [32, 16384] directly, larger "
+                                     "powers of two up to %d in two passes, and every other size from 2 to %d through Bluestein's "
+                                     "algorithm", fft_size, FSEA_MAX_FFT_SIZE, (FSEA_MAX_FFT_SIZE + 1) / 2);
         }
     }
-    if (hop <= 0 || (!blu_m && (hop % 8) != 0)) {
-        return fail(FSEA_EINVAL, "hop must be a positive multiple of 8 (any positive hop for the Bluestein sizes); got %d", hop);
+    if (hop <= 0 || (!blu_m && !fs_n1 && (hop % 8) != 0)) {
+        return fail(FSEA_EINVAL, "hop must be a positive multiple of 8 (any positive hop for the sizes without a kernel of their "
+                                 "own); got %d", hop);
     }
     int count = 0;
     hipError_t ce = hipGetDeviceCount(&count);
@@ -760,6 +905,8 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     p->device = device;
     p->entry = e;
     p->blu_m = blu_m;
+    p->fs_n1 = fs_n1;
+    p->fs_n2 = fs_n2;
     p->num_cu = prop.multiProcessorCount;
     p->no_half_overlap = std::getenv("FSEA_NO_HALF_OVERLAP") != nullptr;
     if (const char *hr = std::getenv("FSEA_HALF_RUN_MAX")) {
@@ -824,7 +971,18 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
             fsea_plan_destroy(p);
             return rc;
         }
-        p->kernel_name = std::string("bluestein(") + p->blu_inner->entry->name[fsea::K_F32] + " x2)";
+        p->kernel_name = std::string("bluestein(") +
+                         (p->blu_inner->fs_n1 ? p->blu_inner->kernel_name : std::string(p->blu_inner->entry->name[fsea::K_F32])) + " x2)";
+    }
+    if (fs_n1) {
+        int rc = create_plan(&p->fs_inner1, fs_n1, fs_n1, FSEA_MODE_COMPLEX_F32, device, "");
+        if (rc == FSEA_OK) rc = create_plan(&p->fs_inner2, fs_n2, fs_n2, FSEA_MODE_COMPLEX_F32, device, "");
+        if (rc == FSEA_OK) rc = fs_setup(p);
+        if (rc != FSEA_OK) {
+            fsea_plan_destroy(p);
+            return rc;
+        }
+        p->kernel_name = std::string("fourstep(") + p->fs_inner1->entry->name[fsea::K_F32] + ", " + p->fs_inner2->entry->name[fsea::K_F32] + ")";
     }
     *out = p;
     return FSEA_OK;
@@ -854,6 +1012,9 @@ int fsea_plan_destroy(fsea_plan *p) {
     DeviceGuard device_guard_(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->blu_inner) (void)fsea_plan_destroy(p->blu_inner);
+    if (p->fs_inner1) (void)fsea_plan_destroy(p->fs_inner1);
+    if (p->fs_inner2) (void)fsea_plan_destroy(p->fs_inner2);
+    if (p->d_fs_tw) (void)hipFree(p->d_fs_tw);
     if (p->d_blu_chirp) (void)hipFree(p->d_blu_chirp);
     if (p->d_blu_dc) (void)hipFree(p->d_blu_dc);
     if (p->d_blu_bfft) (void)hipFree(p->d_blu_bfft);

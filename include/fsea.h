@@ -72,14 +72,17 @@ enum {
 int fsea_device_count(int *count);
 
 /* fft_size: powers of two from 32 to 16384 have kernels of their own (the scripts and tools of the reference use
- * 128 ... 16384).  Every other size from 2 to 8192 -- fftw_plan_dft_1d (src/nrf.c:564) takes any -- runs through
- * Bluestein's algorithm on those kernels: two transforms of size 2^p >= 2 fft_size - 1 around a pointwise product with
- * the chirp's spectrum, three small helper kernels, same modes, same tolerance; such a plan serves fsea_exec_u8_device,
- * the three *_host entry points, the history ring and the gate, but not the tiled and the frequency-shifted entry points
- * (FSEA_EINVAL).  Sizes above 8192 that are not powers of two, and powers of two above 16384, fail with FSEA_EINVAL.
+ * 128 ... 16384).  fftw_plan_dft_1d (src/nrf.c:564) takes any size; the others run on those kernels:
+ *   - powers of two from 32768 to 2^20: two passes of the kernels (four-step: n = n1 n2, column transforms, twiddle,
+ *     row transforms) and three helper kernels;
+ *   - everything else from 2 to 2^19: Bluestein's algorithm, two transforms of size 2^p >= 2 fft_size - 1 around a
+ *     pointwise product with the chirp's spectrum.
+ * Same modes, same tolerance.  Such a plan serves fsea_exec_u8_device, the three *_host entry points, the history ring
+ * and the gate, but not the tiled and the frequency-shifted entry points (FSEA_EINVAL); it is a compatibility path, not
+ * a tuned one.  Larger sizes fail with FSEA_EINVAL.
  * hop: samples between successive frame starts (hop == fft_size: back-to-back
  * frames as in c/fft-batch.c; hop < fft_size: overlapped STFT).  hop must be a
- * positive multiple of 8 for the power-of-two sizes, any positive number for the Bluestein sizes.
+ * positive multiple of 8 for the sizes with kernels of their own, any positive number for the others.
  * device: HIP device ordinal. */
 int fsea_plan_create(fsea_plan **plan, int fft_size, int hop, int mode, int device);
 int fsea_plan_destroy(fsea_plan *plan);

@@ -682,6 +682,34 @@ def test_transform_sizes_fftw_takes_and_the_kernels_do_not(n):
     plan.close()
 
 
+@pytest.mark.parametrize("n", [32768, 65536, 1 << 18, 9000, 20000])
+def test_transform_sizes_above_the_largest_kernel(n):
+    """Powers of two above 16384 run as two passes of the kernels (four-step: n = n1 n2, column transforms, twiddle,
+    row transforms; up to 2^20 points), and sizes above 8192 that are not powers of two through Bluestein's algorithm on
+    top of that.  Against numpy's f64 FFT around the oracle's unpack / magnitude / pixel loops (an O(n^2) DFT of this
+    size takes minutes); same tolerance as every other size."""
+    nf = 2
+    iq = synth_iq(n, 2 * nf * n)
+    for mode in (0, 3, 2):
+        plan = fsea.Plan(n, mode=mode)
+        assert plan.kernel_name.startswith(("fourstep(", "bluestein(fourstep("))
+        got = plan.exec_host(iq, nf)
+        plan.close()
+        want = _expected_rows_any_size(iq, n, nf, n, True, mode, False)
+        if mode == 2:
+            parity.check_u8(got, want)
+            assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
+        else:
+            parity.check_float(got, want)
+    if n == 32768:                       # offset-binary bytes, f64 input, resident data
+        plan = fsea.Plan(n, mode=3)
+        got = plan.exec_host(iq ^ np.uint8(0x80), nf, flip=False)
+        parity.check_float(got, _expected_rows_any_size(iq, n, nf, n, True, 3, False))
+        x = np.random.default_rng(1).normal(0, 0.3, 2 * n)
+        parity.check_float(plan.exec_host_f64(x, 1)[0], np.fft.fft(O.unpack_center_f64(x)))
+        plan.close()
+
+
 def test_nrf_fft_with_a_size_that_is_not_a_power_of_two(history_mode):
     """nrf_fft_new(1000, 4) as a Lua script could ask for (FFTW plans any size): process / get_buffer / shift through the
     reference's API, both history modes."""

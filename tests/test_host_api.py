@@ -93,10 +93,11 @@ def test_plan_argument_validation_messages():
     # argument checks run before any device work, so they are testable without a GPU
     L = fsea.hip_lib()
     p = ctypes.c_void_p()
-    for bad in (9000, 32768, 1, 0, -4):                       # beyond Bluestein's range (2 ... 8192) and not a kernel size
+    for bad in (1, 0, -4, 1 << 21, 600000):                   # beyond four-step (2^20) and Bluestein (2n - 1 <= 2^20)
         assert L.fsea_plan_create(ctypes.byref(p), bad, 8 * max(1, abs(bad)), 0, 0) == -1
         assert b"unsupported fft_size" in L.fsea_last_error_string()
-    assert L.fsea_plan_create(ctypes.byref(p), 1000, 1000, 0, 0) == -2      # a Bluestein size: accepted, then no device here
+    for ok in (1000, 9000, 32768, 1 << 20, 524288, 17):      # Bluestein / four-step sizes: accepted, then no device here
+        assert L.fsea_plan_create(ctypes.byref(p), ok, ok, 0, 0) == -2, ok
     assert L.fsea_plan_create(ctypes.byref(p), 1000, 0, 0, 0) == -1
     assert L.fsea_plan_create(ctypes.byref(p), 1024, 12, 0, 0) == -1
     assert b"multiple of 8" in L.fsea_last_error_string()
