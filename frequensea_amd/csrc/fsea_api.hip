@@ -441,6 +441,11 @@ struct fsea_plan {
     fsea::cf *d_blu_dc = nullptr;            // spectrum of the offset-binary DC term, n entries
     fsea::cf *d_blu_work[2] = {nullptr, nullptr};
     size_t blu_work_frames = 0;
+    // the work buffers are the plan's, not the launch's: launches of such a plan on different streams are put in order
+    // behind one another (an event recorded behind each launch, waited for by the next one's stream)
+    std::mutex work_mu;
+    hipEvent_t work_ev = nullptr;
+    bool work_pending = false;
     // four-step plans (powers of two above 16384): n = fs_n1 * fs_n2, two inner plans, the twiddles W_n^{j2 k1}
     int fs_n1 = 0, fs_n2 = 0;
     fsea_plan *fs_inner1 = nullptr, *fs_inner2 = nullptr;
@@ -574,8 +579,14 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
                                      "entry points exist for the power-of-two sizes from 32 to 16384 only", p->n,
                         p->blu_m ? "Bluestein's algorithm" : "the four-step decomposition");
         }
-        return p->blu_m ? blu_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s)
-                        : fs_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s);
+        std::lock_guard<std::mutex> lock(p->work_mu);
+        if (!p->work_ev) FSEA_HIP(hipEventCreateWithFlags(&p->work_ev, hipEventDisableTiming));
+        if (p->work_pending) FSEA_HIP(hipStreamWaitEvent(s, p->work_ev, 0));
+        const int rc = p->blu_m ? blu_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s)
+                                : fs_launch(p, in_kind, d_in, n_frames, flip, mode, d_out, s);
+        FSEA_HIP(hipEventRecord(p->work_ev, s));
+        p->work_pending = true;
+        return rc;
     }
     return launch_pow2(p, in_kind, d_in, n_frames, flip, mode, d_out, s, rot_delta, rot_phase0, tiles);
 }
@@ -1012,6 +1023,7 @@ int fsea_plan_destroy(fsea_plan *p) {
     DeviceGuard device_guard_(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->blu_inner) (void)fsea_plan_destroy(p->blu_inner);
+    if (p->work_ev) (void)hipEventDestroy(p->work_ev);
     if (p->fs_inner1) (void)fsea_plan_destroy(p->fs_inner1);
     if (p->fs_inner2) (void)fsea_plan_destroy(p->fs_inner2);
     if (p->d_fs_tw) (void)hipFree(p->d_fs_tw);

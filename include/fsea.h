@@ -79,7 +79,9 @@ int fsea_device_count(int *count);
  *     pointwise product with the chirp's spectrum.
  * Same modes, same tolerance.  Such a plan serves fsea_exec_u8_device, the three *_host entry points, the history ring
  * and the gate, but not the tiled and the frequency-shifted entry points (FSEA_EINVAL); it is a compatibility path, not
- * a tuned one.  Larger sizes fail with FSEA_EINVAL.
+ * a tuned one: five to ten launches per batch through work buffers that belong to the plan, so launches of one such plan
+ * on different streams run one after the other (ordered by events), and they cannot be captured into a graph.
+ * Larger sizes fail with FSEA_EINVAL.
  * hop: samples between successive frame starts (hop == fft_size: back-to-back
  * frames as in c/fft-batch.c; hop < fft_size: overlapped STFT).  hop must be a
  * positive multiple of 8 for the sizes with kernels of their own, any positive number for the others.
