@@ -154,3 +154,8 @@
 // 256 points with 64 points per lane (4 lanes per frame, 16 x 16 with four columns: dwordx2 loads, four adjacent bins per
 // lane in the last pass), one wave per workgroup, one wave per SIMD
 #define FSEA_CFG_256_P64 256, 4, 16, 1, 2, 16, 16, 1, 1, true, true, 0, 4096
+// pixel kernels at higher occupancy / finer workgroups (round 3; full u8 kernel sets with the product's pixel epilogue):
+// "t256px": 256 lanes x 16 points, four workgroups per CU = 4 waves per SIMD (round 1's layout: 2-byte loads, 1-byte stores);
+// "f1px": the product layout with one frame per workgroup (two waves, four workgroups per CU)
+#define FSEA_CFG_4096_T256PX 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 6328330
+#define FSEA_CFG_4096_F1PX 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, 6328478
