@@ -12,7 +12,7 @@ cp tests/emu/libfsea_emu.so "$T/orig.so"
 restore() { cp "$T/orig.so" "$R/tests/emu/libfsea_emu.so"; touch "$R/tests/emu/libfsea_emu.so"; rm -rf "$T"; }
 trap restore EXIT
 g++ -std=c++20 -O1 -g0 -fPIC -shared -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -Wno-unknown-pragmas \
-    -Itests/emu -Ifrequensea_amd/csrc tests/emu/emu_main.cpp -o tests/emu/libfsea_emu.so
+    -Itests/emu -Ifrequensea_amd/csrc tests/emu/emu_main.cpp tests/emu/emu_variants_a.cpp tests/emu/emu_variants_b.cpp tests/emu/emu_variants_c.cpp -o tests/emu/libfsea_emu.so
 touch tests/emu/libfsea_emu.so
 ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) \
     python -m pytest tests/test_emu_kernels.py -x -q -p no:cacheprovider \

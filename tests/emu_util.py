@@ -16,12 +16,13 @@ OUT_DTYPE = {0: np.float32, 1: np.uint8, 2: np.uint8, 3: np.complex64, 4: np.flo
 def emu_lib():
     global _EMU
     if _EMU is None:
-        src = os.path.join(ROOT, "tests", "emu", "emu_main.cpp")
-        out = os.path.join(ROOT, "tests", "emu", "libfsea_emu.so")
+        emu = os.path.join(ROOT, "tests", "emu")
+        srcs = [os.path.join(emu, f) for f in ("emu_main.cpp", "emu_variants_a.cpp", "emu_variants_b.cpp", "emu_variants_c.cpp")]
+        out = os.path.join(emu, "libfsea_emu.so")
         csrc = os.path.join(ROOT, "frequensea_amd", "csrc")
-        deps = [src, os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")] + [
+        deps = srcs + [os.path.join(emu, "emu_common.h"), os.path.join(emu, "hip", "hip_runtime.h")] + [
             os.path.join(csrc, f) for f in ("fsea_fft_core.h", "fsea_configs.h", "fsea_configs_tune.h", "fsea_tables.h")] + [
-            os.path.join(ROOT, "tests", "emu", "fsea_pk_asm.h")]
+            os.path.join(emu, "fsea_pk_asm.h")]
         def stale():
             return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
@@ -30,10 +31,18 @@ def emu_lib():
             with open(out + ".lock", "w") as lock:
                 fcntl.flock(lock, fcntl.LOCK_EX)
                 if stale():
+                    from concurrent.futures import ThreadPoolExecutor
+                    flags = ["g++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-Wno-unknown-pragmas", "-I" + emu, "-I" + csrc]
+                    objs = ["%s.%d.o" % (s_[:-4], os.getpid()) for s_ in srcs]
+
+                    def compile_one(pair):
+                        subprocess.check_call(flags + ["-c", pair[0], "-o", pair[1]])
+                    with ThreadPoolExecutor(len(srcs)) as pool:       # the four translation units compile in parallel
+                        list(pool.map(compile_one, zip(srcs, objs)))
                     tmp = "%s.%d.tmp" % (out, os.getpid())
-                    subprocess.check_call(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread",
-                                           "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu"),
-                                           "-I" + csrc, src, "-o", tmp])
+                    subprocess.check_call(["g++", "-shared", "-pthread", "-o", tmp] + objs)
+                    for o in objs:
+                        os.remove(o)
                     os.replace(tmp, out)
         L = ctypes.CDLL(out)
         L.emu_fft.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
