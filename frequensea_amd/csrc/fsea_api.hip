@@ -707,17 +707,57 @@ namespace {
 // are truly asynchronous (the two directions overlap: 2.56 instead of 3.57 ms for 64 MiB in + 128 MiB out on this box,
 // profiles/r03_host_path.txt), pageable ones are staged by the runtime and return when done.  Memory that is pinned
 // already (hipHostMalloc, fsea_host_alloc, registered by the caller) is left alone.
+// Two host threads may hand the same buffer to two plans at once (one capture, two transform sizes): the registration is
+// shared and counted, so that the first call to finish does not unpin pages the other one's copies are still using.
+struct PinRegistry {
+    struct Entry {
+        void *ptr;
+        size_t bytes;
+        int users;
+    };
+    std::mutex mu;
+    std::vector<Entry> live;
+};
+PinRegistry &pin_registry() {
+    static PinRegistry r;
+    return r;
+}
+
 struct PinnedInPlace {
     void *ptr = nullptr;
     PinnedInPlace(const void *p, size_t bytes) {
+        PinRegistry &r = pin_registry();
+        std::lock_guard<std::mutex> lock(r.mu);
+        for (auto &e : r.live) {
+            if (e.ptr == p && e.bytes >= bytes) {  // pinned by a call in flight on another thread: share it
+                ++e.users;
+                ptr = const_cast<void *>(p);
+                return;
+            }
+        }
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return;  // pinned or device
         (void)hipGetLastError();
-        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void *>(p);
-        else (void)hipGetLastError();  // read-only mapping, foreign registration, ...: pageable copies still work
+        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) {
+            ptr = const_cast<void *>(p);
+            r.live.push_back(PinRegistry::Entry{ptr, bytes, 1});
+        } else {
+            (void)hipGetLastError();  // read-only mapping, foreign registration, ...: pageable copies still work
+        }
     }
     ~PinnedInPlace() {
-        if (ptr) (void)hipHostUnregister(ptr);
+        if (!ptr) return;
+        PinRegistry &r = pin_registry();
+        std::lock_guard<std::mutex> lock(r.mu);
+        for (size_t i = 0; i < r.live.size(); ++i) {
+            if (r.live[i].ptr == ptr) {
+                if (--r.live[i].users == 0) {
+                    (void)hipHostUnregister(ptr);
+                    r.live.erase(r.live.begin() + (long)i);
+                }
+                return;
+            }
+        }
     }
     PinnedInPlace(const PinnedInPlace &) = delete;
     PinnedInPlace &operator=(const PinnedInPlace &) = delete;
