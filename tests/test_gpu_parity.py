@@ -443,6 +443,37 @@ def test_half_overlap_kernel_equals_the_ordinary_kernel(n, nf, monkeypatch):
     d_in.free()
 
 
+def test_host_path_from_two_threads_sharing_one_input_buffer():
+    """The pipelined host path pins the caller's pages in place for the call; two host threads handing the SAME capture to
+    two plans at once share one counted registration (the first to finish must not unpin under the other)."""
+    import threading
+    n_a, n_b = 1024, 2048
+    frames = 6000                                   # 12-24 MiB in, 24-48 MiB out: the chunked, three-stream path
+    iq = synth_iq(808, 2 * frames * n_b)
+    plans = {n_a: fsea.Plan(n_a), n_b: fsea.Plan(n_b)}
+    outs = {n: [] for n in plans}
+    errors = []
+
+    def work(n):
+        try:
+            for _ in range(6):
+                outs[n].append(plans[n].exec_host(iq, frames))
+        except Exception as e:                      # pragma: no cover - reported below
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(n,)) for n in plans]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for n, got in outs.items():
+        for g in got[1:]:
+            assert np.array_equal(g, got[0])
+        for f in (0, frames // 2, frames - 1):
+            parity.check_mode(got[0][f:f + 1], iq[2 * f * n:], n, 1, n, True, 0)
+        plans[n].close()
+
+
 def test_calls_leave_the_current_device_alone():
     """Every entry point runs on the plan's device and restores the caller's current HIP device
     (ADVICE r01); with one GPU the observable part is that it stays 0 and nothing fails."""
