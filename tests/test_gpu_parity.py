@@ -443,6 +443,44 @@ def test_half_overlap_kernel_equals_the_ordinary_kernel(n, nf, monkeypatch):
     d_in.free()
 
 
+def test_per_thread_default_stream_from_two_threads():
+    """hipStreamPerThread is ONE handle that names a different stream in every host thread.  Launches on it never
+    keep a ticket-counter slot (each takes a free one, recycled by event), so two threads launching long launches of one
+    plan on their per-thread streams at the same time do not share a slot."""
+    import threading
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    per_thread = 2                                   # hipStreamPerThread
+    n, nf = 8192, 1200
+    plan = fsea.Plan(n)
+    plan.set_unit_distribution(fsea.UNITS_TICKETS)
+    iqs = [synth_iq(60 + k, 2 * nf * n) for k in range(2)]
+    d_in = [DeviceBuffer(iq.nbytes).upload(iq) for iq in iqs]
+    d_out = [DeviceBuffer(nf * n * 4) for _ in range(2)]
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(25):
+                plan.exec_device(d_in[k].ptr, nf, d_out[k].ptr, stream=per_thread)
+            assert hip.hipStreamSynchronize(ctypes.c_void_p(per_thread)) == 0
+        except Exception as e:                      # pragma: no cover - reported below
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        got = d_out[k].download(np.float32, (nf, n))
+        for f in (0, 1, nf // 2, nf - 1):
+            parity.check_float(got[f], O.rows(iqs[k][2 * f * n: 2 * (f + 1) * n], 1, n)[0])
+        d_in[k].free()
+        d_out[k].free()
+    plan.close()
+
+
 def test_host_path_from_two_threads_sharing_one_input_buffer():
     """The pipelined host path pins the caller's pages in place for the call; two host threads handing the SAME capture to
     two plans at once share one counted registration (the first to finish must not unpin under the other)."""
