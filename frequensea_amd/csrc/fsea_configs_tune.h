@@ -159,3 +159,7 @@
 // "f1px": the product layout with one frame per workgroup (two waves, four workgroups per CU)
 #define FSEA_CFG_4096_T256PX 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 6328330
 #define FSEA_CFG_4096_F1PX 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, 6328478
+// 32 and 64 points with two adjacent samples per lane in pass 0 (dword loads instead of 2-byte loads): 4 x 8 and 8 x 8
+#define FSEA_CFG_32_C2 32, 4, 64, 2, 2, 4, 8, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_64_C2 64, 4, 64, 2, 2, 8, 8, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_64_T2 64, 2, 128, 2, 2, 8, 8, 1, 1, true, true, 0, 6295552
