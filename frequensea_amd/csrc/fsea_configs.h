@@ -15,7 +15,10 @@
 #define FSEA_CFG_128 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, 6295552
 #define FSEA_CFG_256 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 6295552
 #define FSEA_CFG_512 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, 6295552
-#define FSEA_CFG_1024 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 6295562
+// 1024 points: round 3 moved from 32 x 32 (2-byte pass-0 loads, one pixel / one f32 bin per lane and store) to 8 x 16 x 8:
+// dwordx2 loads, four adjacent bins per lane in the last pass (dword pixel stores, 16-byte f32 stores), deferred middle-pass
+// twiddles; a second exchange, still no barrier (profiles/r03_1024_three_pass.txt: DB5 / DB10 pixels +6...8 %, f32 rows +1 %)
+#define FSEA_CFG_1024 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328478
 #define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 6328350
 // multi-wave frames: 32 points per lane (4096: two waves per frame, two frames per workgroup), the
 // middle pass's twiddles deferred and register-resident (OPT 128)

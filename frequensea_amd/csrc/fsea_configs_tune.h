@@ -151,6 +151,7 @@
 #define FSEA_CFG_256_PK 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 2101248
 #define FSEA_CFG_256_PX0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 4096
 #define FSEA_CFG_1024_PX0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 4106
+#define FSEA_CFG_1024_R2 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 6295562   /* the round-2 layout (32 x 32) with round 3's pixel epilogue */
 // 256 points with 64 points per lane (4 lanes per frame, 16 x 16 with four columns: dwordx2 loads, four adjacent bins per
 // lane in the last pass), one wave per workgroup, one wave per SIMD
 #define FSEA_CFG_256_P64 256, 4, 16, 1, 2, 16, 16, 1, 1, true, true, 0, 4096
@@ -163,3 +164,12 @@
 #define FSEA_CFG_32_C2 32, 4, 64, 2, 2, 4, 8, 1, 1, true, true, 0, 6295552
 #define FSEA_CFG_64_C2 64, 4, 64, 2, 2, 8, 8, 1, 1, true, true, 0, 6295552
 #define FSEA_CFG_64_T2 64, 2, 128, 2, 2, 8, 8, 1, 1, true, true, 0, 6295552
+// 1024 points in three passes with dword / dwordx2 pass-0 loads (the product's 32 x 32 loads 2 bytes per lane and row):
+// "e" = 16 x 8 x 8, "f" = 8 x 16 x 8, "g" = 16 x 16 x 4; 32 lanes x 32 points, no barrier (single-wave frames), two exchanges
+#define FSEA_CFG_1024_E 1024, 32, 8, 2, 3, 16, 8, 8, 1, true, true, 0, 6328350
+#define FSEA_CFG_1024_F 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328350
+#define FSEA_CFG_1024_G 1024, 32, 8, 2, 3, 16, 16, 4, 1, true, true, 0, 6328350
+#define FSEA_CFG_1024_H 1024, 32, 8, 2, 3, 8, 8, 16, 1, true, true, 0, 6328350
+#define FSEA_CFG_1024_FD 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328478   /* f + deferred middle-pass twiddles */
+#define FSEA_CFG_1024_F0 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328334   /* f without the middle-pass lane rotation (OPT 16) */
+#define FSEA_CFG_1024_FL 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6295582   /* f without nt loads */

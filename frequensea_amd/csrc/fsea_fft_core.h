@@ -588,8 +588,13 @@ struct FftKernel {
     // row bytes, f32 rows in 64-byte pieces 1.04x -- while the default policy lets L2 assemble the line from the
     // neighbouring rows' pieces first: 128-point DB10 pixels 0.205 -> 0.117 ms per 256 MiB of samples.  So only
     // pieces of a whole line or more are stored nt (profiles/r02_store_policy_by_piece_size.txt).
+    // The same goes for a lane whose CL adjacent elements need more than one 16-byte store (four complex bins = 32 bytes:
+    // the 1024- and 2048-point layouts in COMPLEX_F32 mode): each of the two instructions then writes every other 16 bytes of
+    // the row, half a line at a time -- as nt stores 2.3x slower than the default policy, which lets L2 put the halves
+    // together (0.58 -> 0.25 ms per 2^27 samples at 1024 points; found when 1024 moved to four bins per lane in round 3, and
+    // 2048 had had it since round 1).
     template <int ELEM_BYTES>
-    static constexpr int st_aux() { return (T * CL * ELEM_BYTES >= 128) ? ST_AUX : (ST_AUX & ~2); }
+    static constexpr int st_aux() { return (T * CL * ELEM_BYTES >= 128 && CL * ELEM_BYTES <= 16) ? ST_AUX : (ST_AUX & ~2); }
     // OPT 32768: the input loads are streaming (nt) as well
     static constexpr int LD_AUX = (Cfg::OPT & 32768) ? 2 : 0;
     static constexpr bool DEFER = (Cfg::OPT & 128) != 0 && NP == 3;

@@ -21,5 +21,8 @@ int emu_variants_a(int n, const std::string &v, int in_kind, int mt, const fsea:
         EMU_VARIANT(2048, "nr", FSEA_CFG_2048_LR)
         EMU_VARIANT(8192, "twe", FSEA_CFG_8192_TWE)
         EMU_VARIANT(4096, "twe", FSEA_CFG_4096_TWE)
+    EMU_VARIANT(1024, "r2", FSEA_CFG_1024_R2)
+    EMU_VARIANT(1024, "e", FSEA_CFG_1024_E)
+    EMU_VARIANT(1024, "h", FSEA_CFG_1024_H)
     return -2;
 }

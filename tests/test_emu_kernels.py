@@ -120,7 +120,7 @@ def test_edge_inputs():
                                        (1024, "r1"), (1024, "x0"), (1024, "B"), (1024, "C"), (1024, "D"),
                                        (16384, "r1"), (16384, "nd"), (16384, "B"), (256, "p16"), (128, "p16"),
                                        (4096, "w64"), (4096, "w64b"), (4096, "s2"), (4096, "pk"), (4096, "px0"), (8192, "pk"), (8192, "px0"),
-                                       (256, "pk"), (256, "px0"), (1024, "px0"), (256, "p64")])
+                                       (256, "pk"), (256, "px0"), (1024, "px0"), (256, "p64"), (1024, "r2"), (1024, "e"), (1024, "h")])
 def test_tuning_variants(n, variant):
     """Every kernel variant compiled into libfsea_hip_tune.so (fsea_plan_create_variant) stays correct."""
     nf = 9 if n <= 1024 else 3
