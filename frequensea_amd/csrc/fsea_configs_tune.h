@@ -173,3 +173,15 @@
 #define FSEA_CFG_1024_FD 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328478   /* f + deferred middle-pass twiddles */
 #define FSEA_CFG_1024_F0 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328334   /* f without the middle-pass lane rotation (OPT 16) */
 #define FSEA_CFG_1024_FL 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6295582   /* f without nt loads */
+// Round 3, after 1024 gained from wider pass-0 loads and four bins per lane: the same question at the other sizes
+// (full u8 kernel sets with the product's options; names = the radix order)
+#define FSEA_CFG_512_888 512, 16, 16, 2, 3, 8, 8, 8, 1, true, true, 0, 6328478
+#define FSEA_CFG_512_1632 512, 16, 16, 2, 2, 16, 32, 1, 1, true, true, 0, 6328330
+#define FSEA_CFG_256_488 256, 8, 32, 2, 3, 4, 8, 8, 1, true, true, 0, 6328478
+#define FSEA_CFG_256_884 256, 8, 32, 2, 3, 8, 8, 4, 1, true, true, 0, 6328478
+#define FSEA_CFG_128_448 128, 4, 64, 2, 3, 4, 4, 8, 1, true, true, 0, 6328478
+#define FSEA_CFG_2048_81616 2048, 64, 4, 2, 3, 8, 16, 16, 1, true, true, 0, 6328478
+#define FSEA_CFG_4096_16328 4096, 128, 2, 2, 3, 16, 32, 8, 1, true, true, 0, 6328510
+#define FSEA_CFG_4096_83216 4096, 128, 2, 2, 3, 8, 32, 16, 1, true, true, 0, 6328510
+#define FSEA_CFG_8192_163216 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 6328478
+#define FSEA_CFG_8192_83232 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 6328478
