@@ -23,7 +23,9 @@ Extra objects on that line:
                 baseline, not the target.
   extra         the same measurement at N=1024 (the other size BASELINE.json names), and short runs of
                 BASELINE.json's other single-GPU configurations (16384-point 50 %-overlap STFT, the
-                fft-batch-broad sweep with stitch).
+                fft-batch-broad sweep with stitch), the PCIe-inclusive host-buffer entry point, and BASELINE
+                config 2 (nrf_fft(1024, 1024): nrf_fft_process + nrf_fft_get_buffer per rendered frame through
+                libfsea_nrf.so; the oracle's restatement of the reference's CPU loop is cpu_baseline.nrf_stream).
 
 PyTorch is plumbing only here: device buffers, streams, torch.distributed.
 """
@@ -425,6 +427,53 @@ def host_path_rate(n, frames):
     return {"host_path_frames_per_sec_n%d" % n: frames / dt, "host_path_ms_per_batch_n%d" % n: 1e3 * dt}
 
 
+def nrf_stream_rate(n=1024, h=1024, frames=300):
+    """BASELINE config 2 (configs[1]): the nrf_* API as lua/fft.lua:34-45 drives it -- nrf_fft_new(1024, 1024), then per
+    rendered frame nrf_fft_process(one 262144-byte device block) + nrf_fft_get_buffer() (a fresh copy of the whole f64
+    history) -- through libfsea_nrf.so, host-memory block in, malloc'd nut_buffer out.  Informational, never `value`."""
+    from frequensea_amd import nrf
+    L = nrf.nrf_lib()
+    block = np.random.default_rng(2).integers(0, 256, nrf.NRF_BUFFER_SIZE_BYTES, dtype=np.uint8)
+    buf = L.nut_buffer_new_u8(nrf.NRF_SAMPLES_LENGTH, 2, block.ctypes.data)
+    fft = L.nrf_fft_new(n, h)
+    for _ in range(20):
+        L.nrf_fft_process(fft, buf)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        L.nrf_fft_process(fft, buf)
+    t1 = time.perf_counter()
+    for _ in range(frames):
+        L.nrf_fft_process(fft, buf)
+        L.nut_buffer_free(L.nrf_fft_get_buffer(fft))
+    t2 = time.perf_counter()
+    L.nrf_fft_free(fft)
+    L.nut_buffer_free(buf)
+    return {"nrf_fft_%dx%d_process_us" % (n, h): (t1 - t0) / frames * 1e6,
+            "nrf_fft_%dx%d_process_get_buffer_us" % (n, h): (t2 - t1) / frames * 1e6,
+            "nrf_fft_%dx%d_rendered_frames_per_sec" % (n, h): frames / (t2 - t1)}
+
+
+def cpu_nrf_stream(n=1024, h=1024, frames=40):
+    """The same per-frame work as the reference does it on the CPU (src/nrf.c:598-635: unpack and centre ALL 131072
+    samples of the block, one N-point transform, scroll the f64 history down one row, magnitudes, deep copy of the history),
+    from the oracle's restatements; part of the cpu_baseline leg."""
+    from oracle import oracle as O
+    block = np.random.default_rng(2).integers(0, 256, 262144, dtype=np.uint8)
+    history = np.zeros((h, n))
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        x = O.unpack_center_u8(block)
+        spec = O.fft_forward(np.ascontiguousarray(x[:n]))
+        O.history_scroll(history, n, h)
+        history[0, :] = O.mag_row(spec)
+        out = history.copy()
+    dt = time.perf_counter() - t0
+    del out
+    return {"process_get_buffer_us": dt / frames * 1e6, "rendered_frames_per_sec": frames / dt, "cores": 1,
+            "what": "nrf_fft(%d,%d) per rendered frame, oracle restatement of src/nrf.c:598-635 (the reference is single-threaded "
+                    "here; its powf(-1, ii) per sample is a sign select in the restatement, so the reference itself is slower)" % (n, h)}
+
+
 def skeleton_rates():
     import subprocess
     script = os.path.join(ROOT, "scripts", "skeleton_rates.py")
@@ -464,6 +513,18 @@ def effective_cpus():
     return cpus, note
 
 
+def _cpu_model():
+    """Model name of the host's CPU (reported next to the core count), or None."""
+    try:
+        with open("/proc/cpuinfo") as fp:
+            for line in fp:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(n, hop, cores, budget_s):
     """The reference-shaped CPU loop (flip -> unpack/centre -> FFT -> magnitude, oracle/fsea_oracle.c)
     timed on this host, bounded sample of about `budget_s` core-seconds.  The transform is done by an
@@ -496,7 +557,7 @@ def cpu_baseline(n, hop, cores, budget_s):
     out = dict(value=frames / tm, unit="frames/s", cores=cores, kind="port",
                sample="%d frames (%d passes over a %d-frame synthetic N=%d batch, frames sharded over %d threads, "
                       "one plan per thread); %s" % (frames, reps, buf_frames, n, cores, fft_name),
-               one_thread=one_thread)
+               one_thread=one_thread, host_cpus_visible=os.cpu_count(), cpu_model=_cpu_model())
     if fftw is not None:                                     # the oracle's own FFT beside it, short sample
         t = O.time_mag_rows(iq, buf_frames, n, hop, threads=cores)
         out["oracle_fft_value"] = buf_frames / t
@@ -648,6 +709,7 @@ def main():
         line["extra"].update({"broad_sweep_1gpu_frames_per_sec": br["value"], "broad_sweep_1gpu_ms": br["ms_per_step"],
                               "broad_sweep_roofline_frac": br["roofline"]["frac"]})
         line["extra"].update(host_path_rate(n, frames))
+        line["extra"].update(nrf_stream_rate())
         # what bounds the headline kernel from above on THIS box, same launch shape and buffer rotation: its I/O skeleton
         # and a plain 1 : 2 read/write stream (tuning library, in a subprocess: scripts/skeleton_rates.py)
         sk = skeleton_rates()
@@ -664,6 +726,8 @@ def main():
         cb = cpu_baseline(n, hop, cores, args.cpu_budget)
         if quota_note:
             cb["sample"] += "; " + quota_note
+        if not args.no_extra and args.workload == "batch8192x4096":
+            cb["nrf_stream"] = cpu_nrf_stream()
         line["cpu_baseline"] = cb
         line["gpu_over_cpu_all_cores"] = value / cb["value"]
 

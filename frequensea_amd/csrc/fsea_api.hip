@@ -725,38 +725,41 @@ PinRegistry &pin_registry() {
 }
 
 struct PinnedInPlace {
-    void *ptr = nullptr;
+    std::vector<void *> held;  // registrations this call keeps alive: its own, or those of calls in flight that it overlaps
     PinnedInPlace(const void *p, size_t bytes) {
         PinRegistry &r = pin_registry();
         std::lock_guard<std::mutex> lock(r.mu);
+        const char *lo = static_cast<const char *>(p), *hi = lo + bytes;
         for (auto &e : r.live) {
-            if (e.ptr == p && e.bytes >= bytes) {  // pinned by a call in flight on another thread: share it
-                ++e.users;
-                ptr = const_cast<void *>(p);
-                return;
+            const char *elo = static_cast<const char *>(e.ptr), *ehi = elo + e.bytes;
+            if (lo < ehi && elo < hi) {  // pinned (in part) by a call in flight on another thread: its pages must stay
+                ++e.users;               // pinned until this call's copies are done as well
+                held.push_back(e.ptr);
             }
         }
+        if (!held.empty()) return;  // fully covered: asynchronous copies; partly: the runtime stages what is pageable
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return;  // pinned or device
         (void)hipGetLastError();
         if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) {
-            ptr = const_cast<void *>(p);
-            r.live.push_back(PinRegistry::Entry{ptr, bytes, 1});
+            held.push_back(const_cast<void *>(p));
+            r.live.push_back(PinRegistry::Entry{const_cast<void *>(p), bytes, 1});
         } else {
             (void)hipGetLastError();  // read-only mapping, foreign registration, ...: pageable copies still work
         }
     }
     ~PinnedInPlace() {
-        if (!ptr) return;
+        if (held.empty()) return;
         PinRegistry &r = pin_registry();
         std::lock_guard<std::mutex> lock(r.mu);
-        for (size_t i = 0; i < r.live.size(); ++i) {
-            if (r.live[i].ptr == ptr) {
+        for (void *ptr : held) {
+            for (size_t i = 0; i < r.live.size(); ++i) {
+                if (r.live[i].ptr != ptr) continue;
                 if (--r.live[i].users == 0) {
                     (void)hipHostUnregister(ptr);
                     r.live.erase(r.live.begin() + (long)i);
                 }
-                return;
+                break;
             }
         }
     }

@@ -207,13 +207,18 @@ while time.time() < t_end:
     mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5]))
     hazard_draw = rng.random() < 0.33
     if hazard_draw:                                # the 16-byte-store kernels, long launches
-        n = int(rng.choice([64, 128, 2048]))
+        n = int(rng.choice([64, 128, 1024, 2048]))
         mode = int(rng.choice([0, 0, 3, 4, 5]))
-    hop = n if (hazard_draw or rng.random() < 0.7) else int(rng.choice([n // 2, n // 4, 2 * n, 8]))
-    hop = max(8, hop - hop % 8)
+    anysize = (not hazard_draw) and rng.random() < 0.04
+    if anysize:                                    # sizes without a kernel of their own: Bluestein / four-step (plan-owned work buffers)
+        n = int(rng.choice([48, 1000, 1023, 6000, 32768]))
+    hop = n if (hazard_draw or anysize or rng.random() < 0.7) else int(rng.choice([n // 2, n // 4, 2 * n, 8]))
+    hop = max(8, hop - hop % 8) if not anysize else n
     esz = {0: 4, 1: 1, 2: 1, 3: 8, 4: 4, 5: 4}[mode]
     nf_max = min((MAX_IN - 2 * n) // (2 * hop) + 1, (4 * MAX_IN) // (esz * n))
     nf = int(min(nf_max, rng.choice([1, 2, 3, 7, 64, 511, 4096, 20000, 70000])))
+    if anysize:
+        nf = min(nf, 300)
     if hazard_draw:
         nf = int(min(nf_max, max(nf, (1 << 23) // n)))
     flip = bool(rng.integers(2))
@@ -224,11 +229,11 @@ while time.time() < t_end:
     plan = plans[key]
     plan.set_unit_distribution(int(rng.integers(3)))
     tiled, shape, shift = False, None, None
-    if rng.random() < 0.12:                        # the frequency shifter fused into the load (fsea_exec_u8_shifted_device)
+    if rng.random() < 0.12 and not anysize:        # the frequency shifter fused into the load (fsea_exec_u8_shifted_device)
         shift = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0, 1)))
         plan.exec_shifted_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], shift[0], shift[1], flip=flip,
                                  stream=streams[si].value)
-    elif hop == n and rng.random() < 0.2:            # rows into an image, tiles side by side
+    elif hop == n and not anysize and rng.random() < 0.2:            # rows into an image, tiles side by side
         fpw = 1 if n >= 8192 else 2 if n == 4096 else 4 if n == 2048 else 8 if n == 1024 else 16 if n == 512 else 64
         rows_t = fpw * int(rng.integers(1, 4))
         tiles = max(1, min(nf // rows_t, 6))

@@ -62,6 +62,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     ex = d["extra"]
     assert ex["host_path_frames_per_sec_n8192"] > 0 and "two_stream_frames_per_sec_n8192" not in ex
     assert 0.1 < ex["stft16384_roofline_frac"] < 1.0 and 0.1 < ex["broad_sweep_roofline_frac"] < 1.0
+    # BASELINE config 2, the nrf_* API per rendered frame, with the oracle's restatement of the reference's loop beside it
+    assert 0 < ex["nrf_fft_1024x1024_process_us"] < ex["nrf_fft_1024x1024_process_get_buffer_us"] < 5000
     cb = d["cpu_baseline"]
     assert cb["unit"] == "frames/s" and cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert isinstance(cb["sample"], str) and cb["sample"]
+    assert cb["host_cpus_visible"] >= cb["cores"] and cb["nrf_stream"]["process_get_buffer_us"] > 0
