@@ -453,11 +453,10 @@ def nrf_stream_rate(n=1024, h=1024, frames=300):
             "nrf_fft_%dx%d_rendered_frames_per_sec" % (n, h): frames / (t2 - t1)}
 
 
-def cpu_nrf_stream(n=1024, h=1024, frames=40):
+def cpu_nrf_stream(O, n=1024, h=1024, frames=40):
     """The same per-frame work as the reference does it on the CPU (src/nrf.c:598-635: unpack and centre ALL 131072
     samples of the block, one N-point transform, scroll the f64 history down one row, magnitudes, deep copy of the history),
-    from the oracle's restatements; part of the cpu_baseline leg."""
-    from oracle import oracle as O
+    from the oracle's restatements (`O`, handed in by cpu_baseline: the one function of this file that imports it)."""
     block = np.random.default_rng(2).integers(0, 256, 262144, dtype=np.uint8)
     history = np.zeros((h, n))
     t0 = time.perf_counter()
@@ -525,7 +524,7 @@ def _cpu_model():
     return None
 
 
-def cpu_baseline(n, hop, cores, budget_s):
+def cpu_baseline(n, hop, cores, budget_s, nrf_stream=False):
     """The reference-shaped CPU loop (flip -> unpack/centre -> FFT -> magnitude, oracle/fsea_oracle.c)
     timed on this host, bounded sample of about `budget_s` core-seconds.  The transform is done by an
     FFTW3-API library when the host has one -- the reference's own calls, fftw_plan_dft_1d +
@@ -561,6 +560,8 @@ def cpu_baseline(n, hop, cores, budget_s):
     if fftw is not None:                                     # the oracle's own FFT beside it, short sample
         t = O.time_mag_rows(iq, buf_frames, n, hop, threads=cores)
         out["oracle_fft_value"] = buf_frames / t
+    if nrf_stream:
+        out["nrf_stream"] = cpu_nrf_stream(O)
     return out
 
 
@@ -723,11 +724,10 @@ def main():
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cores, quota_note = effective_cpus()
-        cb = cpu_baseline(n, hop, cores, args.cpu_budget)
+        cb = cpu_baseline(n, hop, cores, args.cpu_budget,
+                          nrf_stream=not args.no_extra and args.workload == "batch8192x4096")
         if quota_note:
             cb["sample"] += "; " + quota_note
-        if not args.no_extra and args.workload == "batch8192x4096":
-            cb["nrf_stream"] = cpu_nrf_stream()
         line["cpu_baseline"] = cb
         line["gpu_over_cpu_all_cores"] = value / cb["value"]
 

@@ -288,7 +288,7 @@ unsigned *counter_slot(fsea_plan *p, hipStream_t s, int *index, bool *record) {
         int oldest = -1;
         for (unsigned i = 0; i < FSEA_CTR_SLOTS && pick < 0; ++i) {
             fsea_plan::CtrSlot &c = p->slots[i];
-            if (c.captured) continue;
+            if (c.captured || c.launching) continue;  // launching: claimed by another host thread whose kernel is being enqueued
             if (!c.pending || hipEventQuery(c.ev) == hipSuccess) {
                 if (pick < 0 || c.seq < p->slots[pick].seq) pick = (int)i;
             } else {
@@ -312,6 +312,7 @@ unsigned *counter_slot(fsea_plan *p, hipStream_t s, int *index, bool *record) {
         if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     }
     c.seq = ++p->slot_seq;
+    c.launching = true;  // until launch_pow2 has enqueued the kernel and recorded the slot's event
     *index = pick;
     *record = !capturing;
     return p->d_ctr + (size_t)FSEA_CTR_WORDS * (size_t)pick;
@@ -416,12 +417,16 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
         if (!a.ctr) return fail(FSEA_EHIP, "no ticket-counter slot for this launch (event creation failed, or %u captured streams)", FSEA_CTR_SLOTS);
     }
     e->launch(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
-    FSEA_HIP(hipGetLastError());
-    if (slot >= 0 && record) {
+    const hipError_t launched = hipGetLastError();
+    if (slot >= 0) {
         std::lock_guard<std::mutex> lock(p->slot_mu);
-        FSEA_HIP(hipEventRecord(p->slots[slot].ev, s));
-        p->slots[slot].pending = true;
+        p->slots[slot].launching = false;
+        if (record && launched == hipSuccess) {
+            FSEA_HIP(hipEventRecord(p->slots[slot].ev, s));
+            p->slots[slot].pending = true;
+        }
     }
+    if (launched != hipSuccess) return fail(FSEA_EHIP, "kernel launch failed: %s", hipGetErrorString(launched));
     return FSEA_OK;
 }
 
@@ -591,7 +596,7 @@ int fsea_plan_reset(fsea_plan *p) {
     FSEA_HIP(hipDeviceSynchronize());
     {
         std::lock_guard<std::mutex> lock(p->slot_mu);
-        for (auto &c : p->slots) c.used = c.pending = c.anonymous = c.captured = false;
+        for (auto &c : p->slots) c.used = c.pending = c.anonymous = c.captured = c.launching = false;
     }
     return FSEA_OK;
 }

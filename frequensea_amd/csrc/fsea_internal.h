@@ -84,6 +84,7 @@ struct fsea_plan {
         hipStream_t stream = nullptr;   // the stream the slot serves (meaningful while `used` and not `anonymous`)
         hipEvent_t ev = nullptr;        // recorded behind the slot's last launch (not while the stream is being captured)
         bool used = false, pending = false, anonymous = false, captured = false;
+        bool launching = false;         // claimed by a host thread between counter_slot() and the record of `ev`: not to be recycled
         unsigned long long seq = 0;     // launch order, for least-recently-used recycling
     } slots[FSEA_CTR_SLOTS];
     unsigned long long slot_seq = 0;
