@@ -149,7 +149,7 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
     # Informational only (never `value`): the same steps issued alternately on two streams, so that
     # one launch's drain overlaps the next one's ramp -- what a double-buffered consumer would see.
     two_stream = None
-    if world == 1 and args.two_stream:
+    if world == 1 and (args.two_stream or not args.no_extra) and workload.startswith("batch"):
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         torch.cuda.synchronize()
         for k in range(max(8, warmup)):
@@ -584,7 +584,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--two-stream", action="store_true",
-                    help="also time the steps issued alternately on two streams (informational, in `extra`)")
+                    help="(default since round 3, kept for old command lines) the steps issued alternately on two streams, in `extra`")
     ap.add_argument("--cpu-budget", type=float, default=16.0, help="core-seconds for the CPU sample")
     args = ap.parse_args()
 
@@ -697,9 +697,10 @@ def main():
                          "msamples_per_sec_n1024": ex["frames"] / (ex["kernel_ms"] * 1e-3) * ex["hop"] / 1e6,
                          "roofline_frac_n1024": exb / (ex["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_n1024": ex["kernel"], "avg_launch_ms_n1024": ex["kernel_ms"]}
-        if args.two_stream:
-            line["extra"].update({"two_stream_frames_per_sec_n8192": res["two_stream"],
-                                  "two_stream_frames_per_sec_n1024": ex["two_stream"]})
+        # the same steps issued alternately on two streams (one launch's drain overlaps the next one's ramp): what a
+        # double-buffered consumer of independent batches gets; informational, never `value` (host wall clock)
+        line["extra"].update({"two_stream_frames_per_sec_n8192": res["two_stream"],
+                              "two_stream_frames_per_sec_n1024": ex["two_stream"]})
         # BASELINE.json's other single-GPU-measurable configurations, shorter runs (informational)
         st_steps = max(10, min(args.steps, 300))
         st = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2)

@@ -60,7 +60,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     if "io_skeleton_frac" in roof:
         assert roof["frac"] < roof["io_skeleton_frac"] * 1.05 < roof["copy_frac"] * 1.3 and roof["copy_frac"] < 1.0
     ex = d["extra"]
-    assert ex["host_path_frames_per_sec_n8192"] > 0 and "two_stream_frames_per_sec_n8192" not in ex
+    assert ex["host_path_frames_per_sec_n8192"] > 0
+    # independent batches on two streams: one launch's drain under the next one's ramp; beside `value`, never in it
+    assert 0.9 * d["value_wall"] < ex["two_stream_frames_per_sec_n8192"] < 1.3 * d["value"]
     assert 0.1 < ex["stft16384_roofline_frac"] < 1.0 and 0.1 < ex["broad_sweep_roofline_frac"] < 1.0
     # BASELINE config 2, the nrf_* API per rendered frame, with the oracle's restatement of the reference's loop beside it
     assert 0 < ex["nrf_fft_1024x1024_process_us"] < ex["nrf_fft_1024x1024_process_get_buffer_us"] < 5000
