@@ -40,6 +40,7 @@ extern "C" int fsea_kernels_tune_px(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_big(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_w64(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_lay(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_pw(fsea::KernelEntry *out, int cap);
 #endif
 
 namespace {
@@ -71,7 +72,7 @@ const std::vector<fsea::KernelEntry> &registry() {
 #ifdef FSEA_TUNE
                                                     fsea_kernels_tune_8192a, fsea_kernels_tune_8192b,
                                                     fsea_kernels_tune_abl, fsea_kernels_tune_px, fsea_kernels_tune_mid, fsea_kernels_tune_big,
-                                                    fsea_kernels_tune_w64, fsea_kernels_tune_lay,
+                                                    fsea_kernels_tune_w64, fsea_kernels_tune_lay, fsea_kernels_tune_pw,
 #endif
         };
         for (auto fn : lists) {

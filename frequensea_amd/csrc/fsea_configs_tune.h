@@ -185,3 +185,16 @@
 #define FSEA_CFG_4096_83216 4096, 128, 2, 2, 3, 8, 32, 16, 1, true, true, 0, 6328510
 #define FSEA_CFG_8192_163216 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 6328478
 #define FSEA_CFG_8192_83232 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 6328478
+// OPT 8388608: the last butterfly level of the last pass in power form (dft_regs_tw_pw) in the MAG / DB10 / DB5 kernels;
+// "pw" = the product configuration + that bit; the small sizes do not fuse the last pass's twiddles (OPT 8) in the
+// product, which the power form builds on: "f8" = product + OPT 8, "pw" = product + OPT 8 + power form
+#define FSEA_CFG_8192_PW 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 14717086
+#define FSEA_CFG_16384_PW 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 14717064
+#define FSEA_CFG_4096_PW 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 14717118
+#define FSEA_CFG_2048_PW 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 14716958
+#define FSEA_CFG_1024_PW 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 14717086
+#define FSEA_CFG_512_F8 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, 6295560
+#define FSEA_CFG_512_PW 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, 14684168
+#define FSEA_CFG_256_F8 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 6295560
+#define FSEA_CFG_256_PW 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 14684168
+#define FSEA_CFG_128_PW 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, 14684168

@@ -170,6 +170,74 @@ __device__ __forceinline__ void dft_regs_tw(cf *x, const cf *tw, float sc0) {
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
 
+// ---- the last level in power form (OPT 8388608; fsea_pk_asm.h) ----
+// Where a row only ever leaves as |X|^2 (MAG rows, dB pixels), the last butterfly level of the last pass does not form
+// its two complex outputs: for the pair (y[k], y[k + R/2]) with the constant twiddle W_R^k it forms the planar pairs
+// (x0.re, x1.re) and (x0.im, x1.im) -- two packed ops for w = 1 / -i, four for a general w, against 2 / 3 -- and from
+// them both powers in two packed ops instead of v_mul + v_fmac per bin: one VALU op less per pair with a general
+// twiddle, two with a trivial one.  pp[k S] = (|X_k|^2, |X_{k + R/2}|^2).  x0 is bit-identical to bfly_const's;
+// x1 = a - w b is formed directly (two roundings) instead of 2 a - x0 (three).
+// dc_hi (DC = true, pair 0 only): added to both components of x1 -- the restored offset-binary DC term of bin N/2
+// (FftKernel::epilogue), for the one lane and mode that keep it; zero elsewhere.
+template <int L, int K, bool DC = false>
+__device__ __forceinline__ cf bfly_power(cf a, cf b, float dc_hi = 0.0f) {
+    cf re, im;
+    if constexpr (K == 0) {
+        re = pk_pm_re(a, b);
+        im = pk_pm_im(a, b);
+    } else if constexpr (4 * K == L) {
+        re = pk_pm_re_mi(a, b);
+        im = pk_pm_im_mi(a, b);
+    } else {
+        constexpr int m = K * (64 / L);
+        constexpr float wr = cos64(m), wi = -sin64(m);
+        const cf w = cf{wr, wi};
+        re = pk_pm_re_w(a, b, w);
+        im = pk_pm_im_w(a, b, w);
+    }
+    if constexpr (DC) {
+        re[1] += dc_hi;
+        im[1] += dc_hi;
+    }
+    return cf_fma(re, re, im * im);  // the order of the scalar form: fma(re, re, im * im)
+}
+template <int R, int S, bool DC, int K = 0>
+__device__ __forceinline__ void dft_power_level(const cf *y, cf *pp, float dc_hi) {
+    if constexpr (K < R / 2) {
+        if constexpr (K == 0) pp[0] = bfly_power<R, 0, DC>(y[0], y[R / 2], dc_hi);
+        else pp[K * S] = bfly_power<R, K>(y[K], y[K + R / 2]);
+        dft_power_level<R, S, DC, K + 1>(y, pp, dc_hi);
+    }
+}
+template <int R, int HALF, int STOP, bool MI>
+__device__ __forceinline__ void dft_const_levels_below(cf *y) {
+    if constexpr (HALF < STOP) {
+        dft_const_level<R, HALF, MI>(y);
+        dft_const_levels_below<R, 2 * HALF, STOP, MI>(y);
+    }
+}
+// dft_regs_tw with the last level in power form: x is consumed, pp[k S] (k < R/2) receives the powers
+template <int R, int S, int TS, bool MI = true, bool DC = false>
+__device__ __forceinline__ void dft_regs_tw_pw(const cf *x, const cf *tw, float sc0, cf *pp, float dc_hi = 0.0f) {
+    static_assert(R >= 4 && R <= 64 && (R & (R - 1)) == 0, "radix must be 4..64");
+    constexpr int BITS = ilog2c(R);
+    cf y[R];
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+        cf a = x[i * S];
+        if (i == 0) {
+            if (sc0 != 1.0f) a = a * cf{sc0, sc0};
+        } else {
+            a = pk_cmul(a, tw[(i - 1) * TS]);
+        }
+        const cf plus = pk_cmul_add(x[(i + R / 2) * S], tw[(i + R / 2 - 1) * TS], a);
+        y[bitrev_c(i, BITS)] = plus;
+        y[bitrev_c(i + R / 2, BITS)] = cf_fma(a, cf{2.0f, 2.0f}, -plus);
+    }
+    dft_const_levels_below<R, 2, R / 2, MI>(y);
+    dft_power_level<R, S, DC>(y, pp, dc_hi);
+}
+
 // The same twiddled DFT with the inter-pass twiddles deferred into the butterfly levels
 // (polynomial form): with x_i scaled by om^i (om = W^k, one value per lane), y_k = P(om W_R^k),
 // P(z) = sum x_i z^i = E(z^2) + z O(z^2).  The level that merges sub-transforms of size `half`
@@ -600,6 +668,11 @@ struct FftKernel {
     static constexpr bool DEFER = (Cfg::OPT & 128) != 0 && NP == 3;
     static constexpr bool TK_LATE = (Cfg::OPT & 512) != 0 && NP >= 3 && !ONE_WAVE && (Cfg::ABL & 2) == 0;
     static constexpr bool MI = (Cfg::OPT & 256) == 0;  // OPT 256: the +-i butterflies as packed FMAs by (+-1, -+1) (round-1 form)
+    // OPT 8388608: the last butterfly level in power form (dft_regs_tw_pw) in the kernels whose rows are powers only:
+    // the compile-time MAG / DB10 / DB5 kernels of the V1 schedule with register-resident, fused last-pass twiddles
+    static constexpr bool PW = (Cfg::OPT & 8388608) != 0 && (Cfg::OPT & (64 | 1048576)) == 0 && Cfg::TWR && (Cfg::OPT & 8) != 0 &&
+                               Cfg::ABL == 0 && RL >= 4 &&
+                               (MODE_T == MODE_MAG || MODE_T == MODE_DB10_U8 || MODE_T == MODE_DB5_U8_DCFIX);
     static constexpr bool PX_PACK = (Cfg::OPT & 2097152) != 0;   // pixel epilogue: v_trunc + v_cvt_pk_u8_f32
     static constexpr bool PX_BIAS = (Cfg::OPT & 4194304) != 0;   // ... without the v_trunc (biased round-to-nearest)
     static constexpr bool LANE_ROT = (Cfg::OPT & 16) != 0;       // middle passes
@@ -855,7 +928,25 @@ struct FftKernel {
 
     // fused epilogue for the row held as v[r*CL + c] = bin CL t + c + r NsL.
     // out: window of this unit's rows; lane_elem = slot * N + CL * t (first bin of this lane)
-    static __device__ __forceinline__ void epilogue(int mode, rsrc_t out, uint32_t lane_elem, cf *v, int t) {
+    // |v[r CL + c]|^2, or -- PW -- the power the last level left in pp[(r mod RL/2) CL + c] (fsea::dft_power_level)
+    static __device__ __forceinline__ float bin_power(const cf *v, [[maybe_unused]] const cf *pp, int r, int c) {
+        if constexpr (PW) {
+            return pp[(r % (RL / 2)) * CL + c][r / (RL / 2)];
+        } else {
+            const cf z = v[r * CL + c];
+            return __builtin_fmaf(z[0], z[0], z[1] * z[1]);
+        }
+    }
+    // the restored DC term of bin N/2 for the lane and mode that keep it (see epilogue), else 0: what PW kernels hand to
+    // the power form of the last level, which has no complex bin to add it to afterwards
+    static __device__ __forceinline__ float dc_restore(int mode, int t) {
+        const bool patched = (mode == MODE_MAG) || (mode == MODE_DB5_U8_DCFIX);
+        return (IN == IN_U8 && !patched && t == 0) ? (PRESCALED ? 0.5f : 128.0f) * (float)N : 0.0f;
+    }
+    static constexpr bool PW_DC = PW && IN == IN_U8 && MODE_T == MODE_DB10_U8;
+
+    static __device__ __forceinline__ void epilogue(int mode, rsrc_t out, uint32_t lane_elem, cf *v, int t,
+                                                    [[maybe_unused]] const cf *pp = nullptr) {
         constexpr float SE = PRESCALED ? 1.0f : SC;  // scale still to apply to re / im
         constexpr float SE2 = SE * SE;
         const bool patched = (mode == MODE_MAG) || (mode == MODE_DB5_U8_DCFIX);
@@ -863,7 +954,7 @@ struct FftKernel {
         // (-1)^n centring moves to bin N/2 exactly: 0.5 N (1 + i).  The kernel
         // transforms (u - 128) instead and restores that bin analytically in
         // the modes that keep it.
-        if (IN == IN_U8 && !patched && t == 0) {
+        if (!PW && IN == IN_U8 && !patched && t == 0) {
             const float dc = (PRESCALED ? 0.5f : 128.0f) * (float)N;
             v[(RL / 2) * CL] += cf{dc, dc};
         }
@@ -888,8 +979,7 @@ struct FftKernel {
                 [[maybe_unused]] uint32_t pxw[(CL + 3) / 4] = {};
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
-                    const cf z = v[r * CL + c];
-                    float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
+                    float p = bin_power(v, pp, r, c);
                     if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
                     // The reference's "+ 1e-20" only keeps log10 finite: in f32 it changes p by less than
                     // half an ulp whenever the pixel is not clamped to 0 anyway (p > 1e-13), and for
@@ -945,14 +1035,15 @@ struct FftKernel {
         } else if (mode == MODE_DB_F32) {
             // two loops, one transcendental each: written as `mode == MODE_DB_F32 ? log : sqrt` per element the compiler
             // turns the uniform test into v_log_f32 + v_sqrt_f32 + v_cndmask for every bin
-            f32_rows<true>(patched, out, lane_elem, v, t);
+            f32_rows<true>(patched, out, lane_elem, v, t, pp);
         } else {
-            f32_rows<false>(patched, out, lane_elem, v, t);
+            f32_rows<false>(patched, out, lane_elem, v, t, pp);
         }
     }
 
     template <bool LOG>
-    static __device__ __forceinline__ void f32_rows(bool patched, rsrc_t out, uint32_t lane_elem, cf *v, int t) {
+    static __device__ __forceinline__ void f32_rows(bool patched, rsrc_t out, uint32_t lane_elem, cf *v, int t,
+                                                    [[maybe_unused]] const cf *pp) {
         constexpr float SE = PRESCALED ? 1.0f : SC;
         constexpr float SE2 = SE * SE;
         const uint32_t voff = lane_elem * 4u;
@@ -963,13 +1054,12 @@ struct FftKernel {
             float m[CL];
 #pragma unroll
             for (int c = 0; c < CL; ++c) {
-                const cf z = v[r * CL + c];
-                float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
+                float p = bin_power(v, pp, r, c);
                 if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
                 if constexpr (LOG) {
                     m[c] = (10.0f * 0.30102999566398120f) * __builtin_amdgcn_logf(p + 1.0e-20f);
                 } else if constexpr (Cfg::ABL & 128) {  // ABL 128 (measurement only): no magnitude arithmetic
-                    m[c] = z[0];
+                    m[c] = v[r * CL + c][0];
                 } else {
                     m[c] = __builtin_amdgcn_sqrtf(p);
                 }
@@ -1765,7 +1855,13 @@ struct FftKernel {
             lds_read<LAST>(lds, v, tl);
             after_reads();
             if constexpr (!LAZY_SYNC) frame_sync();  // the buffer is free for the next frame's pass 0
-            if constexpr (Cfg::TWR && TW_FUSE) {
+            [[maybe_unused]] cf pp[PW ? (RL / 2) * CL : 1];
+            if constexpr (PW) {
+                const float dc_hi = PW_DC ? dc_restore(mode, tl) : 0.0f;
+                dft_regs_tw_pw<RL, CL, CL, MI, PW_DC>(v, twl, PRESCALED ? SC : 1.0f, pp, dc_hi);
+#pragma unroll
+                for (int c = 1; c < CL; ++c) dft_regs_tw_pw<RL, CL, CL, MI, false>(v + c, twl + c, PRESCALED ? SC : 1.0f, pp + c);
+            } else if constexpr (Cfg::TWR && TW_FUSE) {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs_tw<RL, CL, CL, MI>(v + c, twl + c, PRESCALED ? SC : 1.0f);
             } else if constexpr (Cfg::TWR) {
@@ -1788,7 +1884,7 @@ struct FftKernel {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0, MI>(v + c);
             }
-            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(RUNS ? fcur : u * FPW), total_out), out_elem, v, tl);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(RUNS ? fcur : u * FPW), total_out), out_elem, v, tl, pp);
             u = un;
             if constexpr (RUNS) {
                 fcur = fnext;

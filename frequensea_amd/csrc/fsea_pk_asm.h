@@ -64,6 +64,49 @@ __device__ __forceinline__ cf pk_cmul_add_mi(cf a, cf w, cf c) {
 }
 
 
+// ---- the last butterfly level in "power form" (FftCfg OPT 8388608) ----
+// For the butterfly pair x0 = a + w b, x1 = a - w b of the last level of the last pass, whose outputs only ever enter
+// |x|^2, the two results are formed planar instead of as two complex values: re = (x0.re, x1.re), im = (x0.im, x1.im),
+// so that |x0|^2 and |x1|^2 are ONE v_pk_mul_f32 + ONE v_pk_fma_f32 for the pair instead of v_mul + v_fmac per bin.
+// The broadcasts and the one-lane negations are op_sel / neg modifiers; operation order per component is the one of
+// bfly_const (x0 bit-identical; x1 = a - w b directly instead of 2 a - x0).
+// w = 1
+__device__ __forceinline__ cf pk_pm_re(cf a, cf b) {  // (a.x + b.x, a.x - b.x)
+    cf t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ cf pk_pm_im(cf a, cf b) {  // (a.y + b.y, a.y - b.y)
+    cf t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+// w = -i: w b = (b.y, -b.x)
+__device__ __forceinline__ cf pk_pm_re_mi(cf a, cf b) {  // (a.x + b.y, a.x - b.y)
+    cf t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+__device__ __forceinline__ cf pk_pm_im_mi(cf a, cf b) {  // (a.y - b.x, a.y + b.x)
+    cf t;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+// constant w = (w.x, w.y), wavefront-uniform in an SGPR pair: w b = (w.x b.x - w.y b.y, w.x b.y + w.y b.x)
+__device__ __forceinline__ cf pk_pm_re_w(cf a, cf b, cf w) {  // (a.x + (w b).x, a.x - (w b).x)
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,0] neg_hi:[0,1,0]" : "=v"(t) : "v"(b), "s"(w), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(b), "s"(w));
+    return t;
+}
+__device__ __forceinline__ cf pk_pm_im_w(cf a, cf b, cf w) {  // (a.y + (w b).y, a.y - (w b).y)
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(t) : "v"(b), "s"(w), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(t) : "v"(b), "s"(w));
+    return t;
+}
+
+
 // ---- cross-lane and byte primitives of the single-wave 64 x 64 schedule (FftKernel::run_w64) ----
 // v_permlane32_swap_b32: lanes 32-63 of `a` trade places with lanes 0-31 of `b` (a half exchange; the other two
 // halves stay).  The builtin lets hipcc place the wait states its operands need behind a VALU write.

@@ -30,6 +30,20 @@ static inline cf pk_cmul_add_mi(cf a, cf w, cf c) {
     return t;
 }
 
+// the last butterfly level in power form (planar results of a butterfly pair)
+static inline cf pk_pm_re(cf a, cf b) { return cf{a[0] + b[0], a[0] - b[0]}; }
+static inline cf pk_pm_im(cf a, cf b) { return cf{a[1] + b[1], a[1] - b[1]}; }
+static inline cf pk_pm_re_mi(cf a, cf b) { return cf{a[0] + b[1], a[0] - b[1]}; }
+static inline cf pk_pm_im_mi(cf a, cf b) { return cf{a[1] - b[0], a[1] + b[0]}; }
+static inline cf pk_pm_re_w(cf a, cf b, cf w) {
+    cf t = cf{fmaf(b[0], w[0], a[0]), fmaf(b[0], -w[0], a[0])};
+    return cf{fmaf(b[1], -w[1], t[0]), fmaf(b[1], w[1], t[1])};
+}
+static inline cf pk_pm_im_w(cf a, cf b, cf w) {
+    cf t = cf{fmaf(b[1], w[0], a[1]), fmaf(b[1], -w[0], a[1])};
+    return cf{fmaf(b[0], w[1], t[0]), fmaf(b[0], -w[1], t[1])};
+}
+
 
 // cross-lane primitives of the single-wave 64 x 64 schedule: every lane of the emulated wavefront publishes its
 // value, then reads the lane it needs (emu_main.cpp)

@@ -130,6 +130,31 @@ def test_tuning_variants(n, variant):
         parity.check_mode(got, iq, n, nf, n, True, mode)
 
 
+@pytest.mark.parametrize("n,variant", [(8192, "pw"), (16384, "pw"), (4096, "pw"), (2048, "pw"), (1024, "pw"), (512, "pw"), (512, "f8"),
+                                       (256, "pw"), (256, "f8"), (128, "pw")])
+def test_last_level_in_power_form(n, variant):
+    """OPT 8388608: the compile-time MAG / DB10 / DB5 kernels form |X|^2 of the last level's butterfly pairs planar
+    (fsea::dft_power_level) instead of two complex outputs each.  Every mode that uses it, both byte conventions' DC
+    handling (DB10 keeps bin N/2: the restored offset-binary DC term goes into the power form), overlapped frames."""
+    nf = 9 if n <= 1024 else 3
+    iq = synth_iq(n + 77, 2 * nf * n)
+    for mode in (0, 1, 2):
+        got = emu_rows(iq, n, nf, mode=mode, grid=2, specialised=True, variant=variant)
+        parity.check_mode(got, iq, n, nf, n, True, mode)
+    # near-constant offset-binary input: bin N/2 carries 0.5 N (1 + i), which DB10 pixels keep (255 there) and the
+    # patched modes overwrite with their left neighbour
+    quiet = (np.random.default_rng(n).integers(-2, 3, 2 * nf * n) + 128).astype(np.uint8) ^ np.uint8(0x80)
+    for mode in (1, 2, 0):
+        got = emu_rows(quiet, n, nf, mode=mode, grid=2, specialised=True, variant=variant)
+        parity.check_mode(got, quiet, n, nf, n, True, mode)
+        if mode == 1:
+            assert (got[:, n // 2] == 255).all() and (got[:, n // 2 - 1] < 200).all()
+    hop = n // 2
+    iq2 = synth_iq(n + 78, 2 * ((nf - 1) * hop + n))
+    got = emu_rows(iq2, n, nf, hop=hop, mode=2, grid=2, specialised=True, variant=variant)
+    parity.check_mode(got, iq2, n, nf, hop, True, 2)
+
+
 def test_random_geometry_sweep():
     """Seeded random draws of (size, hop, frame count, mode, flip, grid): overlapped, gapped
     (hop > N) and tiny hops, ragged frame counts, every epilogue."""
