@@ -198,3 +198,11 @@
 #define FSEA_CFG_256_F8 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 6295560
 #define FSEA_CFG_256_PW 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 14684168
 #define FSEA_CFG_128_PW 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, 14684168
+// 32 / 64 points with two lanes per frame (16 / 32 points per lane): radix orders by pass-0 load width and bins per lane
+//   32: "t2a" 4 x 8 (8-byte loads, 2 bins per lane), "t2b" 8 x 4 (dword loads, 4 bins), "t2c" 2 x 16 (16-byte loads, 1 bin)
+//   64: "t2c" 16 x 4 (dword loads, 8 bins per lane), "t2d" 4 x 16 (16-byte loads, 2 bins)
+#define FSEA_CFG_32_T2A 32, 2, 128, 2, 2, 4, 8, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_32_T2B 32, 2, 128, 2, 2, 8, 4, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_32_T2C 32, 2, 128, 2, 2, 2, 16, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_64_T2C 64, 2, 128, 2, 2, 16, 4, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_64_T2D 64, 2, 128, 2, 2, 4, 16, 1, 1, true, true, 0, 6295552
