@@ -41,6 +41,7 @@ extern "C" int fsea_kernels_tune_big(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_w64(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_lay(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_tune_pw(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_tune_win(fsea::KernelEntry *out, int cap);
 #endif
 
 namespace {
@@ -72,7 +73,7 @@ const std::vector<fsea::KernelEntry> &registry() {
 #ifdef FSEA_TUNE
                                                     fsea_kernels_tune_8192a, fsea_kernels_tune_8192b,
                                                     fsea_kernels_tune_abl, fsea_kernels_tune_px, fsea_kernels_tune_mid, fsea_kernels_tune_big,
-                                                    fsea_kernels_tune_w64, fsea_kernels_tune_lay, fsea_kernels_tune_pw,
+                                                    fsea_kernels_tune_w64, fsea_kernels_tune_lay, fsea_kernels_tune_pw, fsea_kernels_tune_win,
 #endif
         };
         for (auto fn : lists) {
@@ -216,6 +217,20 @@ __global__ void fsea_f64_to_f32_kernel(const double *in, float *out, size_t n) {
 
 namespace {
 
+// the kernel raw int8 input (flip) launches on a plan of a size with kernels of its own
+std::string pow2_kernel_name(const fsea_plan *p) {
+    const fsea::KernelEntry *e = p->entry;
+    const bool windowed = p->window_form != 0;
+    int k = pick_kind(fsea::IN_U8, p->mode, 1);
+    if (windowed) k = (k == fsea::K_U8_MAG) ? fsea::K_U8_MAG_WIN : fsea::K_U8_WIN;
+    if (!e->fn[k]) k = fsea::K_U8;
+    const int half = windowed ? fsea::K_U8_MAG_HALF_WIN : fsea::K_U8_MAG_HALF;
+    if ((k == fsea::K_U8_MAG || k == fsea::K_U8_MAG_WIN) && e->fn[half] && 2 * (size_t)p->hop == (size_t)p->n && !p->no_half_overlap) {
+        k = half;  // 50 %-overlapped frames run the half-overlap kernel
+    }
+    return e->name[k] ? e->name[k] : "";
+}
+
 int ensure(void **ptr, size_t *cap, size_t need) {
     if (*cap >= need) return FSEA_OK;
     if (*ptr) {
@@ -353,12 +368,23 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
     if (n_frames == 0) return FSEA_OK;
     int kind = pick_kind(in_kind, mode, flip);
     const fsea::KernelEntry *e = p->entry;
+    const bool windowed = p->window_form != 0;
+    if (windowed) {
+        if (in_kind != fsea::IN_U8) {
+            return fail(FSEA_EINVAL, "the plan has a taper window: the frequency-shifted and the f64-input entry points take "
+                                     "none (fsea_plan_set_window(plan, NULL) removes it)");
+        }
+        kind = (flip && mode == FSEA_MODE_MAG_F32) ? fsea::K_U8_MAG_WIN : fsea::K_U8_WIN;
+    }
     // tuning variants carry the u8 MAG and run-time-mode kernels only: their pixel modes run the latter
     if (!e->fn[kind] && (kind == fsea::K_U8_DB5 || kind == fsea::K_U8_DB10)) kind = fsea::K_U8;
     if (!e->fn[kind]) {
         return fail(FSEA_EINVAL, "kernel variant '%s' has no entry point for this input kind", e->variant);
     }
     fsea::FftArgs a;
+    a.win = p->d_win;
+    a.win_dc = p->d_win_dc;
+    a.win_offset = p->window_form == 2 ? 1u : 0u;
     a.rot_delta = rot_delta;
     a.rot_phase0 = rot_phase0;
     if (in_kind == fsea::IN_U8_ROT) {
@@ -392,9 +418,10 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
     }
     // 50 %-overlapped frames of the nrf_fft_process kind (raw int8, MAG rows) at the sizes with one frame per workgroup:
     // the half-overlap kernel, runs of consecutive frames per workgroup (every sample loaded once), static units
-    if (kind == fsea::K_U8_MAG && e->launch_half && !tiles && 2 * (size_t)p->hop == (size_t)p->n && n_frames >= 2 &&
-        !p->no_half_overlap) {
-        const size_t wgs = (size_t)p->num_cu * (size_t)(p->occ[fsea::K_U8_MAG_HALF] > 0 ? p->occ[fsea::K_U8_MAG_HALF] : 1);
+    const int half_kind = windowed ? fsea::K_U8_MAG_HALF_WIN : fsea::K_U8_MAG_HALF;
+    if ((kind == fsea::K_U8_MAG || kind == fsea::K_U8_MAG_WIN) && e->fn[half_kind] && !tiles &&
+        2 * (size_t)p->hop == (size_t)p->n && n_frames >= 2 && !p->no_half_overlap) {
+        const size_t wgs = (size_t)p->num_cu * (size_t)(p->occ[half_kind] > 0 ? p->occ[half_kind] : 1);
         size_t run = n_frames / wgs;  // frames per run: long enough to reuse most halves, short enough that every workgroup gets some
         if (run > (size_t)p->half_run_max) run = (size_t)p->half_run_max;
         if (run < 1) run = 1;
@@ -404,7 +431,8 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
         const size_t units = (n_frames + run - 1) / run;
         size_t g = wgs < units ? wgs : units;
         if (g >= 8) g &= ~(size_t)7;
-        e->launch_half(a, (unsigned)g, s);
+        if (windowed) e->launch_win(half_kind, a, (unsigned)g, s);
+        else e->launch_half(a, (unsigned)g, s);
         FSEA_HIP(hipGetLastError());
         return FSEA_OK;
     }
@@ -417,7 +445,8 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
         a.ctr = counter_slot(p, s, &slot, &record);
         if (!a.ctr) return fail(FSEA_EHIP, "no ticket-counter slot for this launch (event creation failed, or %u captured streams)", FSEA_CTR_SLOTS);
     }
-    e->launch(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
+    if (kind >= fsea::K_U8_MAG_WIN) e->launch_win(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
+    else e->launch(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
     const hipError_t launched = hipGetLastError();
     if (slot >= 0) {
         std::lock_guard<std::mutex> lock(p->slot_mu);
@@ -508,14 +537,7 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
         const int v = std::atoi(hr);
         if (v >= 1 && v <= 4096) p->half_run_max = v;
     }
-    {
-        int k = pick_kind(fsea::IN_U8, mode, 1);  // the kernel raw int8 input (flip) launches
-        if (!e->fn[k]) k = fsea::K_U8;
-        p->kernel_name = e->name[k];
-        if (k == fsea::K_U8_MAG && e->launch_half && 2 * (size_t)hop == (size_t)fft_size && !p->no_half_overlap) {
-            p->kernel_name = e->name[fsea::K_U8_MAG_HALF];  // 50 %-overlapped frames run the half-overlap kernel
-        }
-    }
+    p->kernel_name = pow2_kernel_name(p);
 #ifdef FSEA_TUNE
     if (std::getenv("FSEA_TRACE")) {
         if (hipMalloc(reinterpret_cast<void **>(&p->d_trace), 4096 * 32 * sizeof(unsigned long long)) != hipSuccess) {
@@ -617,6 +639,8 @@ int fsea_plan_destroy(fsea_plan *p) {
     if (p->d_blu_work[0]) (void)hipFree(p->d_blu_work[0]);
     if (p->d_blu_work[1]) (void)hipFree(p->d_blu_work[1]);
     if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_win) (void)hipFree(p->d_win);
+    if (p->d_win_dc) (void)hipFree(p->d_win_dc);
     if (p->d_in) (void)hipFree(p->d_in);
     if (p->d_out) (void)hipFree(p->d_out);
     if (p->d_aux) (void)hipFree(p->d_aux);
@@ -654,9 +678,66 @@ int fsea_plan_set_unit_distribution(fsea_plan *p, int policy) {
     return FSEA_OK;
 }
 
+int fsea_window_fill(int kind, int n, float *w) {
+    static const double coef[6][5] = {{1.0, 0, 0, 0, 0},
+                                      {0.5, 0.5, 0, 0, 0},
+                                      {0.54, 0.46, 0, 0, 0},
+                                      {0.42, 0.5, 0.08, 0, 0},
+                                      {0.35875, 0.48829, 0.14128, 0.01168, 0},
+                                      {0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368}};
+    if (kind < FSEA_WINDOW_RECT || kind > FSEA_WINDOW_FLATTOP) return fail(FSEA_EINVAL, "unknown window kind %d", kind);
+    if (n < 1 || !w) return fail(FSEA_EINVAL, "fsea_window_fill: n >= 1 and a buffer of n floats");
+    const double tau = 6.283185307179586476925286766559;
+    for (int j = 0; j < n; ++j) {
+        double v = 0.0, sign = 1.0;
+        for (int k = 0; k < 5; ++k) {
+            if (coef[kind][k] != 0.0) v += sign * coef[kind][k] * std::cos(tau * (double)k * (double)j / (double)n);
+            sign = -sign;
+        }
+        w[j] = (float)v;
+    }
+    return FSEA_OK;
+}
+
+int fsea_plan_window_form(const fsea_plan *p) { return p ? p->window_form : 0; }
+
+int fsea_plan_set_window(fsea_plan *p, const float *w) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    if (p->blu_m || p->fs_n1) {
+        return fail(FSEA_EINVAL, "fft_size %d has no kernel of its own (Bluestein / four-step path): the taper window is fused into "
+                                 "the kernels of the powers of two from 32 to 16384", p->n);
+    }
+    const fsea::KernelEntry *e = p->entry;
+    FSEA_ON_DEVICE(p->device);
+    FSEA_HIP(hipDeviceSynchronize());  // no launch of this plan may still be reading the tables that are replaced
+    if (!w) {
+        p->window_form = 0;
+        p->kernel_name = pow2_kernel_name(p);
+        return FSEA_OK;
+    }
+    if (!e->fn[fsea::K_U8_WIN] || !e->fn[fsea::K_U8_MAG_WIN]) {
+        return fail(FSEA_EINVAL, "kernel variant '%s' of size %d has no windowed kernels", e->variant, p->n);
+    }
+    const int n = p->n;
+    for (int j = 0; j < n; ++j) {
+        if (!std::isfinite(w[j])) return fail(FSEA_EINVAL, "window weight %d is not finite", j);
+    }
+    std::vector<float> perm;
+    std::vector<fsea::TwPair> dc;
+    const int form = fsea::build_window_tables(n, e->t, e->radix[0], e->radix[e->np - 1], w, perm, dc);
+    if (!p->d_win) FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_win), (size_t)n * sizeof(float)));
+    if (!p->d_win_dc) FSEA_HIP(hipMalloc(reinterpret_cast<void **>(&p->d_win_dc), dc.size() * sizeof(fsea::cf)));
+    FSEA_HIP(hipMemcpy(p->d_win, perm.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    FSEA_HIP(hipMemcpy(p->d_win_dc, dc.data(), dc.size() * sizeof(fsea::cf), hipMemcpyHostToDevice));
+    p->window_form = form;
+    p->kernel_name = pow2_kernel_name(p);
+    return FSEA_OK;
+}
+
 int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned *block, size_t *lds_bytes) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
     int k = pick_kind(fsea::IN_U8, p->mode, 1);
+    if (p->window_form) k = (k == fsea::K_U8_MAG) ? fsea::K_U8_MAG_WIN : fsea::K_U8_WIN;
     if (!p->entry->fn[k]) k = fsea::K_U8;
     if (grid) *grid = grid_for(p, p->entry, p->occ[k], n_frames);
     if (block) *block = (unsigned)p->entry->wg;

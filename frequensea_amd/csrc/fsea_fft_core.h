@@ -404,6 +404,18 @@ struct FftArgs {
     // half-overlap kernels (FftKernel<..., RUNS = true>, hop == N/2): a unit is a run of `run_len` consecutive frames, and
     // inside a run the second half of a frame's bytes stays in registers as the first half of the next frame's
     uint32_t run_len = 0;
+    // Taper window (WIN kernels; fsea_plan_set_window): x[n] = (-1)^n w[n] u8[n] / 256 -- the weight slot of
+    // src/nrf.c:611-612, where the reference has the (-1)^n alone.
+    // win: N floats, (-1)^n w[n] in the order the pass-0 lanes hold their samples: weight i = r C0 + c of lane t belongs
+    //      to sample n = C0 t + c + r N/R0 and sits at win[(i / 4) 4 T + 4 t + i % 4] (16-byte loads, the lanes' pieces
+    //      of one load adjacent).
+    // win_dc: the kernels transform w (u8 - 128) and put the offset-binary DC term back as its known spectrum
+    //      0.5 (1 + i) D[k], D = DFT of (-1)^n w: 2 NsL entries for the bins [N/2 - NsL, N/2 + NsL), where a cosine-sum taper
+    //      has all of it.  A window whose D is not confined to that band (win_offset != 0) is applied to the
+    //      offset-binary value itself, w u8, and win_dc is all zero.
+    const float *win = nullptr;
+    const cf *win_dc = nullptr;
+    uint32_t win_offset = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -562,19 +574,26 @@ __device__ __forceinline__ float s8f(uint32_t w, int byte) {
     return (float)(int8_t)(uint8_t)(w >> (8 * byte));
 }
 
+__device__ __forceinline__ float u8f(uint32_t w, int byte) {
+    return (float)(uint8_t)(w >> (8 * byte));
+}
+
 // Convert one raw row to C complex samples in integer units (u - 128); the
 // 1/256 scale is applied later.  (-1)^n is applied here as a negation of odd
 // columns (row strides are even), which the compiler folds into the neg
 // modifiers of the first butterflies.
-// SIGNED = false leaves the (-1)^n out (the frequency-shifted path folds it into its phasors).
-template <int IN, int C, bool SIGNED = true>
+// SIGNED = false leaves the (-1)^n out (the frequency-shifted path folds it into its phasors, the windowed path into its
+// weights).  OFFSET = true: the bytes as offset-binary values 0 .. 255 (xormask ^ 0x80808080 turns either byte convention
+// into them; v_cvt_f32_ubyteN where the centred form takes the sign-extending conversion).
+template <int IN, int C, bool SIGNED = true, bool OFFSET = false>
 __device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t xormask, int j0, cf *dst) {
+    [[maybe_unused]] auto b2f = [](uint32_t w, int byte) { return OFFSET ? u8f(w, byte) : s8f(w, byte); };
     if constexpr (IN == IN_F32) {
 #pragma unroll
         for (int c = 0; c < C; ++c) dst[c] = (SIGNED && ((j0 + c) & 1)) ? -raw.w[c] : raw.w[c];
     } else if constexpr (C == 1) {
         const uint32_t w = (uint32_t)raw.w ^ xormask;
-        const cf z = cf{s8f(w, 0), s8f(w, 1)};
+        const cf z = cf{b2f(w, 0), b2f(w, 1)};
         dst[0] = (SIGNED && (j0 & 1)) ? -z : z;
     } else {
         uint32_t words[C / 2];
@@ -592,8 +611,8 @@ __device__ __forceinline__ void convert_row(const RawRow<IN, C> &raw, uint32_t x
 #pragma unroll
         for (int q = 0; q < C / 2; ++q) {
             const uint32_t w = words[q] ^ xormask;
-            dst[2 * q] = cf{s8f(w, 0), s8f(w, 1)};         // even column: +
-            const cf odd = cf{s8f(w, 2), s8f(w, 3)};
+            dst[2 * q] = cf{b2f(w, 0), b2f(w, 1)};         // even column: +
+            const cf odd = cf{b2f(w, 2), b2f(w, 3)};
             dst[2 * q + 1] = SIGNED ? -odd : odd;          // odd column: -
         }
     }
@@ -625,9 +644,17 @@ __device__ __forceinline__ cf turn_phasor_f32(double turns) {
 // RUNS: the 50 %-overlap form (hop == N/2, BASELINE.json's STFT configuration): a workgroup takes RUNS of consecutive
 // frames, and the second half of every frame's bytes -- pass-0 rows R0/2 .. R0-1 of each lane -- is kept in registers as
 // rows 0 .. R0/2-1 of the next frame, so that every sample is loaded once (FftArgs::run_len frames per run; static units).
-template <class Cfg, int IN, int MODE_T = -1, bool ROT = false, bool RUNS = false>
+// WIN: the taper window fused into pass 0's conversion (fsea_plan_set_window; north_star's "fused unpack+window
+// prologue"): v = (u8 - 128) * ((-1)^n w[n]), one packed multiply per sample behind the byte conversion, the weights two
+// to a register pair as they were loaded.  1 = the lane's P weights are fetched again for every frame (one run of P
+// floats per lane from a table that lives in L2; issued in front of the previous frame's row stores, so that they have
+// arrived when the frame's bytes are converted and hold registers only from there to there), 2 = they stay in registers
+// for the workgroup's lifetime.  The offset-binary DC term is put back behind the last pass from FftArgs::win_dc.
+template <class Cfg, int IN, int MODE_T = -1, bool ROT = false, bool RUNS = false, int WIN = 0>
 struct FftKernel {
     static_assert(!ROT || IN == IN_U8, "the fused frequency shift is a u8-input path");
+    static_assert(WIN == 0 || (IN == IN_U8 && !ROT && Cfg::TWR && (Cfg::OPT & (64 | 1048576 | 8388608)) == 0 && Cfg::P >= 8),
+                  "the windowed kernels: u8 input, V1 schedule, register-resident (prescaled) last-pass twiddles");
     static_assert(!RUNS || (IN == IN_U8 && !ROT && Cfg::FPW == 1 && (Cfg::R(0) % 2) == 0), "half-overlap runs: u8 input, one frame per workgroup");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
     static constexpr int LAST = NP - 1;
@@ -954,7 +981,7 @@ struct FftKernel {
         // (-1)^n centring moves to bin N/2 exactly: 0.5 N (1 + i).  The kernel
         // transforms (u - 128) instead and restores that bin analytically in
         // the modes that keep it.
-        if (!PW && IN == IN_U8 && !patched && t == 0) {
+        if (!PW && WIN == 0 && IN == IN_U8 && !patched && t == 0) {
             const float dc = (PRESCALED ? 0.5f : 128.0f) * (float)N;
             v[(RL / 2) * CL] += cf{dc, dc};
         }
@@ -1124,6 +1151,34 @@ struct FftKernel {
     }
 
     static constexpr bool W64 = (Cfg::OPT & 1048576) != 0;
+
+    // ---- taper window (WIN kernels) ----
+    static constexpr int WPAIRS = WIN ? P / 2 : 1;
+    // LDS of a kernel in complex units: frames, table block, ticket words, and -- windowed kernels -- the DC term's
+    // spectrum for the 2 NsL bins around N/2 (FftArgs::win_dc)
+    static constexpr int DC_OFF = (Cfg::LDS_ALLOC + 1) & ~1;  // 16-byte aligned
+    static constexpr int LDS_CF = WIN ? DC_OFF + 2 * NsL : Cfg::LDS_ALLOC;
+    static constexpr int DC_REGS = (2 * NsL + Cfg::WG - 1) / Cfg::WG;
+    static_assert(WIN == 0 || (Cfg::TWL || Cfg::TWR), "the DC table rides on the table block's barrier");
+    // the lane's P weights, (-1)^n w[n] in the order of its pass-0 registers (FftArgs::win): P/4 16-byte loads, the T
+    // lanes' pieces of one load adjacent in memory
+    static __device__ __forceinline__ void load_window(rsrc_t rs, int t, cf *wv) {
+        const uint32_t voff = (uint32_t)t * 16u;
+#pragma unroll
+        for (int i = 0; i < P / 4; ++i) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (uint32_t)(16 * T * i), 0);
+            wv[2 * i] = cf{u2f(q[0]), u2f(q[1])};
+            wv[2 * i + 1] = cf{u2f(q[2]), u2f(q[3])};
+        }
+    }
+    // pass 0's conversion with the weights applied: v[i] = byte value * weight i
+    template <bool OFFSET>
+    static __device__ __forceinline__ void convert_windowed(const Raw *raw, uint32_t xormask, int t, const cf *wv, cf *v) {
+#pragma unroll
+        for (int r = 0; r < R0; ++r) convert_row<IN, C0, false, OFFSET>(raw[r], OFFSET ? xormask ^ 0x80808080u : xormask, C0 * t, v + r * C0);
+#pragma unroll
+        for (int i = 0; i < P; ++i) v[i] = (i & 1) ? pk_scale_hi(v[i], wv[i / 2]) : pk_scale_lo(v[i], wv[i / 2]);
+    }
 
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
         if constexpr (W64) run_w64(a, lds_all);
@@ -1636,6 +1691,19 @@ struct FftKernel {
         if (dyn) {
             if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
         }
+        // taper window: this lane's weights, and the DC term's spectrum in the band [N/2 - NsL, N/2 + NsL) -- the rows
+        // RL/2 - 1 and RL/2 of the last pass -- on its way to LDS (held in registers it costs spills at 16384 points)
+        [[maybe_unused]] const rsrc_t win_rs = buffer_window(WIN ? a.win : nullptr, 0, WIN ? (size_t)N * 4u : 0);
+        cf wv[WPAIRS];
+        cf dcv[WIN ? DC_REGS : 1];
+        if constexpr (WIN != 0) {
+            load_window(win_rs, t, wv);
+#pragma unroll
+            for (int i = 0; i < DC_REGS; ++i) {
+                const int e = tid + i * Cfg::WG;
+                dcv[i] = a.win_dc[e < 2 * NsL ? e : 2 * NsL - 1];  // clamped, as the table block above
+            }
+        }
 
         // The small twiddle block (middle-pass tables + HI/LO factors, a few KiB) goes to LDS, and
         // the last pass's register-resident twiddles W^{r k}, k = CL t + c, are built from the
@@ -1648,6 +1716,13 @@ struct FftKernel {
                 const int e = tid + i * Cfg::WG;
                 // lanes past the end rewrite the last entry with its own value (loaded clamped above)
                 lds_all[FPW * Cfg::LDS_FRAME + (e < TAB_COPY ? e : TAB_COPY - 1)] = tabv[i];
+            }
+            if constexpr (WIN != 0) {
+#pragma unroll
+                for (int i = 0; i < DC_REGS; ++i) {
+                    const int e = tid + i * Cfg::WG;
+                    lds_all[DC_OFF + (e < 2 * NsL ? e : 2 * NsL - 1)] = dcv[i];
+                }
             }
             if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) a.trace[32 * b + 28] = wall_clock64();  // tables arrived
             __syncthreads();
@@ -1767,6 +1842,9 @@ struct FftKernel {
                         v[r * C0 + c] = pk_cmul(v[r * C0 + c] + cf{128.0f, 128.0f}, pk_cmul_uniform(fr[c], wr));
                     }
                 }
+            } else if constexpr (WIN != 0) {
+                if (a.win_offset != 0) convert_windowed<true>(raw, xormask, t, wv, v);
+                else convert_windowed<false>(raw, xormask, t, wv, v);
             } else {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], xormask, C0 * t, v + r * C0);
@@ -1883,6 +1961,28 @@ struct FftKernel {
             if constexpr (!(Cfg::TWR && TW_FUSE)) {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0, MI>(v + c);
+            }
+            if constexpr (WIN != 0) {
+                // the offset-binary DC term's spectrum, for this lane's bins of the two rows around N/2
+                // (two bins at a time: the 2 CL values in flight at once cost spills at 1024 points, CL = 4)
+                constexpr int CB = CL >= 2 ? 2 : 1;
+#pragma unroll
+                for (int c = 0; c < CL; c += CB) {
+                    cf dc_lo[CB], dc_hi[CB];
+                    ld_c<CB>(lds_all + DC_OFF + CL * tl + c, dc_lo);
+                    ld_c<CB>(lds_all + DC_OFF + NsL + CL * tl + c, dc_hi);
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {
+                        v[(RL / 2 - 1) * CL + c + j] += dc_lo[j];
+                        v[(RL / 2) * CL + c + j] += dc_hi[j];
+                    }
+                }
+                if constexpr (WIN == 1) {
+                    // the next frame's weights: requested in front of this frame's row stores (loads return in order, and a
+                    // wait for a load issued behind the stores would wait for those as well)
+                    load_window(win_rs, t, wv);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(RUNS ? fcur : u * FPW), total_out), out_elem, v, tl, pp);
             u = un;

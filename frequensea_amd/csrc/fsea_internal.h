@@ -133,7 +133,13 @@ struct fsea_plan {
     fsea::cf *d_fs_tw = nullptr;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_in[FSEA_HOST_CHUNKS_MAX] = {}, ev_done[FSEA_HOST_CHUNKS_MAX] = {};
+    // taper window (fsea_plan_set_window): weights in the pass-0 lane order with (-1)^n folded in, and the DC term's
+    // spectrum around bin n/2 (FftArgs::win, win_dc); window_form 0 = none, 1 = centred, 2 = offset-binary
+    float *d_win = nullptr;
+    fsea::cf *d_win_dc = nullptr;
+    int window_form = 0;
     std::string kernel_name;
+    std::string kernel_name_nowin;   // kernel_name while no window is set
 };
 
 

@@ -32,6 +32,19 @@ __device__ __forceinline__ cf pk_cmul_uniform(cf a, cf w) {
     return t;
 }
 
+// a complex value times a real weight: a * wp.x (pk_scale_lo) or a * wp.y (pk_scale_hi), the weight broadcast to both
+// halves by op_sel -- the taper window's multiply: weights stay packed two to a register pair, as they are loaded.
+__device__ __forceinline__ cf pk_scale_lo(cf a, cf wp) {
+    cf t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(wp));
+    return t;
+}
+__device__ __forceinline__ cf pk_scale_hi(cf a, cf wp) {
+    cf t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "v"(a), "v"(wp));
+    return t;
+}
+
 // c + a * w with the same two-instruction shape (the product's first half takes c as addend).
 __device__ __forceinline__ cf pk_cmul_add(cf a, cf w, cf c) {
     cf t;

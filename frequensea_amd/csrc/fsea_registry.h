@@ -16,7 +16,10 @@ namespace fsea {
 // K_F32 takes f32-complex input (the NUT_BUFFER_F64 branch).
 // K_U8_MAG_HALF: the MAG kernel for 50 %-overlapped frames (hop == N/2) of the sizes with one frame per workgroup (8192,
 // 16384): runs of consecutive frames per workgroup, every sample loaded once (FftKernel<..., RUNS = true>).
-enum : int { K_U8_MAG = 0, K_U8_DB5 = 1, K_U8_DB10 = 2, K_U8 = 3, K_U8_ROT = 4, K_F32 = 5, K_U8_MAG_HALF = 6, K_COUNT = 7 };
+// K_U8_MAG_WIN, K_U8_WIN, K_U8_MAG_HALF_WIN: K_U8_MAG, K_U8 and K_U8_MAG_HALF with the taper window fused into pass 0's
+// conversion (FftKernel<..., WIN>; fsea_plan_set_window) -- what a plan with a window launches.
+enum : int { K_U8_MAG = 0, K_U8_DB5 = 1, K_U8_DB10 = 2, K_U8 = 3, K_U8_ROT = 4, K_F32 = 5, K_U8_MAG_HALF = 6,
+             K_U8_MAG_WIN = 7, K_U8_WIN = 8, K_U8_MAG_HALF_WIN = 9, K_COUNT = 10 };
 
 struct KernelEntry {
     int n;                 // transform size
@@ -31,6 +34,7 @@ struct KernelEntry {
     const char *name[K_COUNT];  // symbol names as rocprof shows them
     void (*launch)(int kind, const FftArgs &args, unsigned grid, hipStream_t stream);
     void (*launch_half)(const FftArgs &args, unsigned grid, hipStream_t stream);  // K_U8_MAG_HALF, or null
+    void (*launch_win)(int kind, const FftArgs &args, unsigned grid, hipStream_t stream);  // the *_WIN kinds, or null
 };
 
 // Each k_*.hip translation unit exports `int fsea_kernels_<tag>(KernelEntry *out, int cap)`
@@ -41,7 +45,7 @@ struct KernelEntry {
 #define FSEA_KERNEL_FN_(NAME, SUFFIX, ...)                                                            \
     extern "C" __global__ __launch_bounds__(NAME##_cfg::WG, NAME##_cfg::WPE) void NAME##SUFFIX(       \
         fsea::FftArgs a) {                                                                            \
-        __shared__ __attribute__((aligned(16))) fsea::cf lds[NAME##_cfg::LDS_ALLOC];                  \
+        __shared__ __attribute__((aligned(16))) fsea::cf lds[fsea::FftKernel<NAME##_cfg, __VA_ARGS__>::LDS_CF]; \
         fsea::FftKernel<NAME##_cfg, __VA_ARGS__>::run(a, lds);                                        \
     }
 
@@ -145,6 +149,39 @@ struct KernelEntry {
         return e;                                                                                     \
     }
 #define FSEA_REGISTER_HALF(NAME) if (n < cap) out[n++] = NAME##_entry_half();
+
+// The windowed kernels of a configuration defined above: NAME_u8_mag_win, NAME_u8_win (and NAME_u8_mag_half_win with
+// HALF = 1).  WMODE: FftKernel's WIN (1 = weights fetched per frame, 2 = register-resident).  FSEA_REGISTER_WIN /
+// FSEA_REGISTER_HALF_WIN register the entry with them.
+#define FSEA_DEFINE_WINDOWED(NAME, WMODE)                                                             \
+    FSEA_KERNEL_FN_(NAME, _u8_mag_win, fsea::IN_U8, fsea::MODE_MAG, false, false, WMODE)              \
+    FSEA_KERNEL_FN_(NAME, _u8_win, fsea::IN_U8, -1, false, false, WMODE)                              \
+    static void NAME##_launch_win(int kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {   \
+        const dim3 g(grid), b(NAME##_cfg::WG);                                                        \
+        if (kind == fsea::K_U8_MAG_WIN) hipLaunchKernelGGL(NAME##_u8_mag_win, g, b, 0, s, a);         \
+        else hipLaunchKernelGGL(NAME##_u8_win, g, b, 0, s, a);                                        \
+    }                                                                                                 \
+    static void NAME##_add_win(fsea::KernelEntry &e) {                                                \
+        e.fn[fsea::K_U8_MAG_WIN] = reinterpret_cast<const void *>(&NAME##_u8_mag_win);                \
+        e.fn[fsea::K_U8_WIN] = reinterpret_cast<const void *>(&NAME##_u8_win);                        \
+        e.name[fsea::K_U8_MAG_WIN] = #NAME "_u8_mag_win";                                             \
+        e.name[fsea::K_U8_WIN] = #NAME "_u8_win";                                                     \
+        e.launch_win = &NAME##_launch_win;                                                            \
+    }
+#define FSEA_DEFINE_HALF_OVERLAP_WIN(NAME, WMODE)                                                     \
+    FSEA_KERNEL_FN_(NAME, _u8_mag_half_win, fsea::IN_U8, fsea::MODE_MAG, false, true, WMODE)          \
+    static void NAME##_launch_win_all(int kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) { \
+        if (kind == fsea::K_U8_MAG_HALF_WIN) hipLaunchKernelGGL(NAME##_u8_mag_half_win, dim3(grid), dim3(NAME##_cfg::WG), 0, s, a); \
+        else NAME##_launch_win(kind, a, grid, s);                                                     \
+    }                                                                                                 \
+    static void NAME##_add_half_win(fsea::KernelEntry &e) {                                           \
+        NAME##_add_win(e);                                                                            \
+        e.fn[fsea::K_U8_MAG_HALF_WIN] = reinterpret_cast<const void *>(&NAME##_u8_mag_half_win);      \
+        e.name[fsea::K_U8_MAG_HALF_WIN] = #NAME "_u8_mag_half_win";                                   \
+        e.launch_win = &NAME##_launch_win_all;                                                        \
+    }
+#define FSEA_REGISTER_WIN(NAME) if (n < cap) { out[n] = NAME##_entry(); NAME##_add_win(out[n]); ++n; }
+#define FSEA_REGISTER_HALF_WIN(NAME) if (n < cap) { out[n] = NAME##_entry_half(); NAME##_add_half_win(out[n]); ++n; }
 
 #define FSEA_REGISTER_BEGIN(TAG)                                                                      \
     extern "C" int fsea_kernels_##TAG(fsea::KernelEntry *out, int cap) {                              \

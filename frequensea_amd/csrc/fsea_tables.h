@@ -85,4 +85,78 @@ inline void build_rotation_rows(int n, int r0, double delta, TwPair *rows) {
     }
 }
 
+// Taper window tables of the windowed kernels (FftArgs::win, win_dc; fsea_plan_set_window).  n points over t lanes, first
+// radix r0, last radix rl; w: n weights.
+//   perm: (-1)^j w[j] in the order the pass-0 lanes hold their samples: register i = r c0 + c of lane t is sample
+//         j = c0 t + c + r n/r0 and sits at perm[(i / 4) 4 t_lanes + 4 t + i % 4].
+//   dc:   the spectrum of the offset-binary DC term, S[k] = 0.5 (1 + i) D[k] with D the DFT of (-1)^j w[j] (double,
+//         iterative radix 2), for the 2 nsl bins [n/2 - nsl, n/2 + nsl), nsl = n / rl: the rows rl/2 - 1 and rl/2 of the
+//         last pass.  Entries below 2^-40 of the peak are zero, so that a rectangular w gives the un-windowed kernels' bits.
+// Returns the form: 1 (centred: the kernels transform w (u8 - 128) and add dc) when S is confined to that band, else 2
+// (offset-binary: w u8, dc all zero).  "Confined": the part of S the centred form leaves out -- the bins outside the band
+// -- has an rms of at most 2^-24 sqrt(0.5 sum w^2), half of what the offset-binary form's f32 rounding puts into every bin
+// (relative L2 error of the transform ~1.2e-7, of a spectrum whose energy is the DC term's, n * 0.5 sum w^2).  Cosine-sum
+// tapers rounded to f32 leave ~2e-8 there (the rounding of the weights itself, not confined to any band); Kaiser and
+// truncated Gaussians leave their skirts (1e-6 ... 1e-4) and take form 2.
+inline int build_window_tables(int n, int t_lanes, int r0, int rl, const float *w, std::vector<float> &perm,
+                               std::vector<TwPair> &dc) {
+    const int p = n / t_lanes, c0 = p / r0;
+    perm.assign((size_t)n, 0.0f);
+    for (int t = 0; t < t_lanes; ++t) {
+        for (int r = 0; r < r0; ++r) {
+            for (int c = 0; c < c0; ++c) {
+                const int j = c0 * t + c + r * (n / r0);
+                const int i = r * c0 + c;
+                perm[(size_t)(i / 4) * 4 * (size_t)t_lanes + (size_t)4 * t + (size_t)(i % 4)] = (j & 1) ? -w[j] : w[j];
+            }
+        }
+    }
+    std::vector<double> re((size_t)n), im((size_t)n, 0.0);
+    int bits = 0;
+    while ((1 << bits) < n) ++bits;
+    for (int j = 0; j < n; ++j) {
+        int rj = 0;
+        for (int b = 0; b < bits; ++b) rj |= ((j >> b) & 1) << (bits - 1 - b);
+        re[(size_t)rj] = (j & 1) ? -(double)w[j] : (double)w[j];
+    }
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int len = 2; len <= n; len <<= 1) {
+        const int half = len / 2;
+        for (int k = 0; k < half; ++k) {
+            const double wr = std::cos(two_pi * (double)k / (double)len), wi = -std::sin(two_pi * (double)k / (double)len);
+            for (int base = k; base < n; base += len) {
+                const size_t i0 = (size_t)base, i1 = (size_t)base + (size_t)half;
+                const double tr = re[i1] * wr - im[i1] * wi, ti = re[i1] * wi + im[i1] * wr;
+                re[i1] = re[i0] - tr;
+                im[i1] = im[i0] - ti;
+                re[i0] += tr;
+                im[i0] += ti;
+            }
+        }
+    }
+    const int nsl = n / rl;
+    double peak = 0.0, outside2 = 0.0, w2 = 0.0;
+    int n_outside = 0;
+    for (int k = 0; k < n; ++k) {
+        const double m = std::hypot(0.5 * (re[(size_t)k] - im[(size_t)k]), 0.5 * (re[(size_t)k] + im[(size_t)k]));
+        if (m > peak) peak = m;
+        if (k < n / 2 - nsl || k >= n / 2 + nsl) {
+            outside2 += m * m;
+            ++n_outside;
+        }
+        w2 += (double)w[k] * (double)w[k];
+    }
+    const double rms_outside = n_outside ? std::sqrt(outside2 / n_outside) : 0.0;
+    const int form = (rms_outside <= std::ldexp(std::sqrt(0.5 * w2), -24)) ? 1 : 2;
+    dc.assign((size_t)2 * (size_t)nsl, TwPair{0.f, 0.f});
+    if (form == 1) {
+        for (int j = 0; j < 2 * nsl; ++j) {
+            const size_t k = (size_t)(n / 2 - nsl + j);
+            const double sr = 0.5 * (re[k] - im[k]), si = 0.5 * (re[k] + im[k]);
+            if (std::hypot(sr, si) > std::ldexp(peak, -40)) dc[(size_t)j] = TwPair{(float)sr, (float)si};
+        }
+    }
+    return form;
+}
+
 }  // namespace fsea

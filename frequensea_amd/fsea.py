@@ -14,6 +14,8 @@ MODE_DB5_U8_DCFIX = 2
 MODE_COMPLEX_F32 = 3
 MODE_MAG_NODC_F32 = 4
 MODE_DB_F32 = 5
+WINDOW_RECT, WINDOW_HANN, WINDOW_HAMMING, WINDOW_BLACKMAN, WINDOW_BLACKMANHARRIS, WINDOW_FLATTOP = range(6)
+WINDOW_KINDS = {"rect": 0, "boxcar": 0, "hann": 1, "hamming": 2, "blackman": 3, "blackmanharris": 4, "flattop": 5}
 
 _MODE_DTYPE = {
     MODE_MAG_F32: np.float32, MODE_DB10_U8: np.uint8, MODE_DB5_U8_DCFIX: np.uint8,
@@ -30,6 +32,7 @@ EXPORTS = [
     "fsea_plan_kernel_name", "fsea_last_error_string",
     "fsea_history_create", "fsea_history_destroy", "fsea_history_push_u8_host", "fsea_history_push_f64_host",
     "fsea_history_shift", "fsea_history_get_f64",
+    "fsea_plan_set_window", "fsea_plan_window_form", "fsea_window_fill",
 ]
 # include/fsea_tune.h: only libfsea_hip_tune.so (scripts/tune.py and friends) has these
 TUNE_EXPORTS = ["fsea_plan_create_variant", "fsea_time_exec_u8_device", "fsea_time_exec_u8_rotating",
@@ -124,6 +127,9 @@ def hip_lib():
         L.fsea_stream_synchronize.argtypes = [vp, vp]
         L.fsea_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
         L.fsea_host_free.argtypes = [vp]
+        L.fsea_plan_set_window.argtypes = [vp, vp]
+        L.fsea_plan_window_form.argtypes = [vp]
+        L.fsea_window_fill.argtypes = [ci, ci, vp]
         _LIB = L
     return _LIB
 
@@ -131,6 +137,13 @@ def hip_lib():
 def _check(rc):
     if rc != 0:
         raise FseaError("fsea error %d: %s" % (rc, hip_lib().fsea_last_error_string().decode()))
+
+
+def window(kind, n):
+    """fsea_window_fill: the periodic cosine-sum taper `kind` (a name of WINDOW_KINDS or a number) as n float32 weights."""
+    w = np.empty(n, dtype=np.float32)
+    _check(hip_lib().fsea_window_fill(WINDOW_KINDS[kind] if isinstance(kind, str) else int(kind), n, w.ctypes.data))
+    return w
 
 
 def device_count():
@@ -199,6 +212,23 @@ class Plan:
         tile f // tile_rows, tile k at columns first_x + k * tile_step."""
         _check(self._L.fsea_exec_u8_tiled_device(self._p, d_iq_ptr, n_frames, int(bool(flip)), d_image_ptr, image_rows,
                                                  image_stride, first_x, tile_rows, tile_step, stream or None))
+
+    def set_window(self, w):
+        """fsea_plan_set_window: fft_size float32 weights (a name of WINDOW_KINDS is filled in first), None removes it."""
+        if w is None:
+            _check(self._L.fsea_plan_set_window(self._p, None))
+            return
+        if isinstance(w, str):
+            w = window(w, self.fft_size)
+        wf = np.ascontiguousarray(w, dtype=np.float32).ravel()
+        if wf.size != self.fft_size:
+            raise ValueError("a window has fft_size weights")
+        _check(self._L.fsea_plan_set_window(self._p, wf.ctypes.data))
+
+    @property
+    def window_form(self):
+        """0 = no window, 1 = centred form, 2 = offset-binary form (include/fsea.h)."""
+        return self._L.fsea_plan_window_form(self._p)
 
     def set_unit_distribution(self, policy):
         """UNITS_AUTO (default), UNITS_STATIC or UNITS_TICKETS: fsea_plan_set_unit_distribution."""

@@ -21,6 +21,9 @@
  *                         c/fft-batch-broad.c:81-98
  *   fsea_composite_max_*  tile compositing, c/fft-stitch.c:46-54,
  *                         c/fft-stitch-broad.c:28-36
+ *   fsea_plan_set_window  a taper in the weight slot of the unpack loop: the reference weights each sample by
+ *                         powf(-1, ii) alone (src/nrf.c:611-612, c/fft-batch.c:65-66), i.e. its window is
+ *                         rectangular; this is the optional w[n] beside it, fused into the same conversion
  *   fsea_plan_destroy     replaces fftw_destroy_plan/fftw_free
  *                         src/nrf.c:637-642, c/fft-batch.c:147-152
  *
@@ -88,6 +91,41 @@ int fsea_device_count(int *count);
  * device: HIP device ordinal. */
 int fsea_plan_create(fsea_plan **plan, int fft_size, int hop, int mode, int device);
 int fsea_plan_destroy(fsea_plan *plan);
+
+/* Taper window.  With a window set, every u8 transform of the plan computes
+ *   X[k] = sum_n (-1)^n w[n] (u8[n] / 256) e^{-2 pi i n k / fft_size}
+ * -- the reference's unpack loop (src/nrf.c:601-614) with w[n] beside its powf(-1, ii); w == 1 is the reference
+ * itself -- followed by the plan's epilogue unchanged (MAG and DB5 rows still copy bin n/2 - 1 into bin n/2: with a
+ * taper the offset-binary DC term also reaches the neighbours of bin n/2, as it does in the reference's arithmetic).
+ * The multiply is fused into the kernel's byte conversion (one packed multiply per sample; no extra pass, no extra
+ * HBM traffic: the fft_size weights live in L2 / registers).
+ *   w: fft_size floats, copied; NULL removes the window (rectangular, the un-windowed kernels).  Any finite values.
+ * Applies to fsea_exec_u8_device, fsea_exec_u8_tiled_device, fsea_exec_u8_host, the history ring and the gate.  The
+ * frequency-shifted and the f64-input entry points fail with FSEA_EINVAL on a plan with a window, and so does
+ * fsea_plan_set_window on a plan whose size has no kernel of its own (not a power of two in [32, 16384]).
+ * Synchronous (waits for the device); not to be called while another thread is launching the plan.
+ * Precision: the kernels transform w[n] (u8[n] - 128) and add the offset-binary DC term back as its known spectrum
+ * (computed in double at this call) when that spectrum is confined to the bins around n/2 -- every cosine-sum
+ * taper (Hann, Hamming, Blackman, Blackman-Harris, flat-top; fsea_plan_window_form() == 1; what is left out is the
+ * f32 rounding of the weights themselves, ~2e-8 of the DC term's rms).  Any other w (Kaiser, a truncated Gaussian,
+ * arbitrary values) is applied to the offset-binary values themselves (form 2): same result, f32 rounding noise
+ * relative to the DC term instead of to the signal (~1.2e-7 of the DC term's rms in every bin; inside the stated
+ * tolerance either way). */
+int fsea_plan_set_window(fsea_plan *plan, const float *w);
+/* 0 = no window, 1 = centred form, 2 = offset-binary form (see above). */
+int fsea_plan_window_form(const fsea_plan *plan);
+
+/* Standard tapers in their periodic ("DFT-even") form, w[j] = sum_k (-1)^k a_k cos(2 pi k j / n) -- what
+ * scipy.signal.get_window(name, n) returns -- evaluated in double, rounded to float. */
+enum {
+    FSEA_WINDOW_RECT = 0,
+    FSEA_WINDOW_HANN = 1,            /* 0.5, 0.5 */
+    FSEA_WINDOW_HAMMING = 2,         /* 0.54, 0.46 */
+    FSEA_WINDOW_BLACKMAN = 3,        /* 0.42, 0.5, 0.08 */
+    FSEA_WINDOW_BLACKMANHARRIS = 4,  /* 0.35875, 0.48829, 0.14128, 0.01168 */
+    FSEA_WINDOW_FLATTOP = 5          /* 0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368 */
+};
+int fsea_window_fill(int kind, int n, float *w);
 
 /* Launch geometry the plan would use for n_frames (persistent grid, workgroup
  * size, static LDS bytes per workgroup).  Any out-pointer may be NULL. */

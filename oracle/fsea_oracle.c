@@ -318,6 +318,61 @@ int orc_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip,
     return 0;
 }
 
+/* ---- taper window (extension: BASELINE.json north_star / config 5; the reference's only weight is (-1)^ii) ---- */
+
+int orc_rows_windowed(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                      const double *window, void *out) {
+    orc_plan p;
+    if (window == NULL) return orc_rows(iq, n_frames, n, hop, flip, mode, out);
+    if (mode < 0 || mode > 5) return -2;
+    if (orc_plan_init(&p, n) != 0) return -1;
+    uint8_t *tmp_u8 = (uint8_t *)malloc((size_t)2 * (size_t)n);
+    double *tmp_in = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tmp_out = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    size_t row_bytes = (mode == 1 || mode == 2) ? (size_t)n
+                       : (mode == 3)            ? sizeof(double) * 2 * (size_t)n
+                                                : sizeof(double) * (size_t)n;
+    for (size_t f = 0; f < n_frames; f++) {
+        const uint8_t *src = iq + 2 * f * hop;
+        if (flip) {
+            orc_flip_u8(src, tmp_u8, (size_t)2 * (size_t)n); /* src/nrf.c:100-109 */
+            src = tmp_u8;
+        }
+        orc_unpack_center_u8(src, (size_t)n, tmp_in);        /* src/nrf.c:601-614: (-1)^ii * u8/256.0 */
+        for (int ii = 0; ii < n; ii++) {                      /* ... and the taper beside the (-1)^ii */
+            tmp_in[2 * ii] *= window[ii];
+            tmp_in[2 * ii + 1] *= window[ii];
+        }
+        orc_plan_exec(&p, tmp_in, tmp_out);
+        orc_epilogue(n, mode, tmp_out, (uint8_t *)out + f * row_bytes);
+    }
+    free(tmp_u8);
+    free(tmp_in);
+    free(tmp_out);
+    orc_plan_free(&p);
+    return 0;
+}
+
+int orc_window_fill(int kind, int n, double *w) {
+    static const double coef[6][5] = {{1.0, 0, 0, 0, 0},
+                                      {0.5, 0.5, 0, 0, 0},
+                                      {0.54, 0.46, 0, 0, 0},
+                                      {0.42, 0.5, 0.08, 0, 0},
+                                      {0.35875, 0.48829, 0.14128, 0.01168, 0},
+                                      {0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368}};
+    const double tau = 6.283185307179586476925286766559;
+    if (kind < 0 || kind > 5 || n < 1) return -1;
+    for (int j = 0; j < n; j++) {
+        double v = 0.0, sign = 1.0;
+        for (int k = 0; k < 5; k++) {
+            if (coef[kind][k] != 0.0) v += sign * coef[kind][k] * cos(tau * (double)k * (double)j / (double)n);
+            sign = -sign;
+        }
+        w[j] = v;
+    }
+    return 0;
+}
+
 /* ---- frequency shifter (src/nrf.c:843-866) ------------------------------- */
 
 void orc_freq_shift(const uint8_t *iq_u8, const double *iq_f64, size_t n_samples, int freq_offset,

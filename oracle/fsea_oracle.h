@@ -97,6 +97,21 @@ void orc_composite_max(uint8_t *dst, const uint8_t *src, uint32_t dst_x,
 int orc_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip,
              int mode, void *out);
 
+/* orc_rows with a taper window in the weight slot of the unpack loop.  The reference's loop (src/nrf.c:601-614;
+ * c/fft-batch.c:62-68) weights sample ii by powf(-1, ii) alone; this is the same loop with w[ii] beside it:
+ *   x[ii] = (-1)^ii * window[ii] * (u8[ii] / 256.0)
+ * (window == NULL or all ones: orc_rows itself).  Everything behind the unpack -- transform, magnitude and its
+ * bin n/2 := bin n/2-1 copy, dB pixels -- is the reference's, unchanged.  An EXTENSION named by BASELINE.json
+ * (north_star: "fused unpack+window prologue"; config 5's STFT), not reference behaviour: the reference has no taper
+ * (SURVEY.md section 0). */
+int orc_rows_windowed(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                      const double *window, void *out);
+
+/* The periodic ("DFT-even") cosine-sum tapers, w[j] = sum_k (-1)^k a_k cos(2 pi k j / n): kind 0 rectangular, 1 Hann
+ * (0.5, 0.5), 2 Hamming (0.54, 0.46), 3 Blackman (0.42, 0.5, 0.08), 4 Blackman-Harris, 5 flat-top -- the coefficient
+ * sets of scipy.signal.windows (tests/test_oracle.py checks them against scipy.signal.get_window). */
+int orc_window_fill(int kind, int n, double *w);
+
 /* nrf_freq_shifter_process on interleaved IQ (src/nrf.c:843-866): for every sample,
  *   out_i = vi*cos - vq*sin + 0.5,  out_q = vi*sin + vq*cos + 0.5,
  * then (cos, sin) advance by the angle 2*pi*freq_offset/sample_rate through the reference's own

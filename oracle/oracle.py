@@ -212,6 +212,47 @@ def rows(iq, n_frames, n, hop=None, flip=True, mode=MODE_MAG):
     return out
 
 
+def rows_windowed(iq, n_frames, n, window, hop=None, flip=True, mode=MODE_MAG):
+    """rows() with a taper in the weight slot of the unpack loop: x[j] = (-1)^j window[j] u8[j] / 256."""
+    hop = n if hop is None else hop
+    iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
+    need = 2 * ((n_frames - 1) * hop + n) if n_frames else 0
+    if iq.size < need:
+        raise ValueError("iq too short: %d < %d" % (iq.size, need))
+    w = np.ascontiguousarray(window, dtype=np.float64)
+    if w.size != n:
+        raise ValueError("window must have n weights")
+    if mode in (MODE_DB10_U8, MODE_DB5_U8_DCFIX):
+        out = np.empty((n_frames, n), dtype=np.uint8)
+    elif mode == MODE_COMPLEX:
+        out = np.empty((n_frames, n), dtype=np.complex128)
+    else:
+        out = np.empty((n_frames, n), dtype=np.float64)
+    L = lib()
+    L.orc_rows_windowed.restype = ctypes.c_int
+    L.orc_rows_windowed.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.orc_rows_windowed(iq.ctypes.data, n_frames, n, hop, int(bool(flip)), mode, w.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise ValueError("orc_rows_windowed failed: %d" % rc)
+    return out
+
+
+WINDOW_KINDS = {"rect": 0, "boxcar": 0, "hann": 1, "hamming": 2, "blackman": 3, "blackmanharris": 4, "flattop": 5}
+
+
+def window(kind, n):
+    """Periodic cosine-sum taper of n weights (float64); kind: a name of WINDOW_KINDS or its number."""
+    k = WINDOW_KINDS[kind] if isinstance(kind, str) else int(kind)
+    w = np.empty(n, dtype=np.float64)
+    L = lib()
+    L.orc_window_fill.restype = ctypes.c_int
+    L.orc_window_fill.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    if L.orc_window_fill(k, n, w.ctypes.data) != 0:
+        raise ValueError("orc_window_fill(%r, %d) failed" % (kind, n))
+    return w
+
+
 def freq_shift(iq, freq_offset, sample_rate, state=(1.0, 0.0)):
     """nrf_freq_shifter_process on interleaved IQ (u8 -> u8/256.0, or f64): returns (interleaved f64
     output, new (cosine, sine) state)."""

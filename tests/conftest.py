@@ -19,6 +19,19 @@ def golden():
     return np.load(path)
 
 
+@pytest.fixture(scope="session")
+def golden_all():
+    """Every full-size capture of the reference's rfdata/ (35 files): first 2*8192 bytes, rows at 1024 and 8192, and one
+    capture's whole 262144-byte block with its 128 rows at 1024 (tests/golden/make_golden.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "rfdata_all_golden.npz"))
+
+
+def _all_capture_keys():
+    with np.load(os.path.join(ROOT, "tests", "golden", "rfdata_all_golden.npz")) as z:
+        return sorted(k[:-len("__sha256")] for k in z.files if k.endswith("__sha256"))
+
+
+ALL_CAPTURE_KEYS = _all_capture_keys()
 GOLDEN_KEYS = ["rf_100p900_1", "rf_202p500_1", "rf_202p500_2", "rf_202p500_3"]
 GOLDEN_SIZES = [128, 256, 1024, 4096, 8192, 16384]
 

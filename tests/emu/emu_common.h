@@ -22,8 +22,25 @@ extern thread_local std::barrier<> *g_wave_barrier;
 extern thread_local unsigned *g_wave_slot;   // one word per wave for readfirstlane
 extern thread_local unsigned *g_wave_lanes;  // 64 words per wave for the cross-lane reads
 
-template <class Cfg, int IN, int MODE_T, bool ROT = false, bool RUNS = false>
+// the taper window of the next calls (emu_set_window): weights, and which windowed kernel form runs (FftKernel's WIN: 1 =
+// weights fetched per frame, 2 = register-resident); forced form 0 = as build_window_tables decides, 1 / 2 = that one
+extern std::vector<float> g_window;
+extern int g_window_mode, g_window_form;
+
+template <class Cfg, int IN, int MODE_T, bool ROT = false, bool RUNS = false, int WIN = 0>
 static inline void run_grid(fsea::FftArgs a, unsigned grid) {
+    std::vector<float> win_perm;
+    std::vector<fsea::TwPair> win_dc;
+    if constexpr (WIN != 0) {
+        int form = fsea::build_window_tables(Cfg::N, Cfg::T, Cfg::R(0), Cfg::R(Cfg::NP - 1), g_window.data(), win_perm, win_dc);
+        if (g_window_form == 2 && form == 1) {  // the offset-binary form forced on a window that qualifies for the centred one
+            for (auto &e : win_dc) e = fsea::TwPair{0.f, 0.f};
+            form = 2;
+        }
+        a.win = win_perm.data();
+        a.win_dc = reinterpret_cast<const fsea::cf *>(win_dc.data());
+        a.win_offset = form == 2 ? 1u : 0u;
+    }
     if (ROT) {
         fsea::TwPair rows[32];
         fsea::build_rotation_rows(Cfg::N, Cfg::R(0), a.rot_delta, rows);
@@ -47,7 +64,7 @@ static inline void run_grid(fsea::FftArgs a, unsigned grid) {
     std::vector<unsigned> ctr(9 * 32 + 2048, 0u);
     a.ctr = ctr.data();
     for (unsigned b = 0; b < grid; ++b) {
-        std::vector<fsea::cf> lds_store(Cfg::LDS_ALLOC + 2);
+        std::vector<fsea::cf> lds_store(fsea::FftKernel<Cfg, IN, MODE_T, ROT, RUNS, WIN>::LDS_CF + 2);
         fsea::cf *lds = lds_store.data();
         if (reinterpret_cast<uintptr_t>(lds) & 15) lds += 1;  // 16-byte alignment as on the device
         std::barrier<> bar(Cfg::WG);
@@ -69,7 +86,7 @@ static inline void run_grid(fsea::FftArgs a, unsigned grid) {
                 g_wave_barrier = wbar[t / 64].get();
                 g_wave_slot = &wslot[t / 64];
                 g_wave_lanes = &wlanes[(t / 64) * 64];
-                fsea::FftKernel<Cfg, IN, MODE_T, ROT, RUNS>::run(a, lds);
+                fsea::FftKernel<Cfg, IN, MODE_T, ROT, RUNS, WIN>::run(a, lds);
             });
         }
         for (auto &x : th) x.join();
@@ -92,6 +109,23 @@ static inline int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsi
         else if (mode_t == fsea::MODE_DB10_U8) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB10_U8>(a, grid);
         else run_grid<Cfg, fsea::IN_U8, -1>(a, grid);
         return 0;
+    } else
+    if (!g_window.empty()) {  // windowed kernels: K_U8_MAG_WIN (compile-time MAG), K_U8_WIN, K_U8_MAG_HALF_WIN
+        if constexpr ((Cfg::OPT & (64 | 1048576 | 8388608)) == 0 && Cfg::TWR) {
+            if ((int)g_window.size() != Cfg::N || (in_kind != fsea::IN_U8 && in_kind != 3)) return -5;
+            if (in_kind == 3) {
+                if constexpr (Cfg::FPW == 1 && (Cfg::OPT & 512) == 0) {
+                    if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, true, 1>(a, grid);
+                    else run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, true, 2>(a, grid);
+                } else return -4;
+            } else if (mode_t == fsea::MODE_MAG) {
+                if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, false, 1>(a, grid);
+                else run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, false, 2>(a, grid);
+            } else {
+                if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, -1, false, false, 1>(a, grid);
+                else run_grid<Cfg, fsea::IN_U8, -1, false, false, 2>(a, grid);
+            }
+        } else return -5;
     } else
     if (in_kind == 3) {  // the half-overlap MAG kernel (K_U8_MAG_HALF): hop == N/2, runs of g_run_len frames
         if constexpr (Cfg::FPW == 1 && (Cfg::OPT & (64 | 512 | 1048576)) == 0) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, true>(a, grid);

@@ -34,6 +34,16 @@ extern "C" int emu_fft(int n, int in_kind, int specialised, const void *in, void
     return emu_fft_variant(n, "", in_kind, specialised, in, out, n_frames, hop, flip, mode, grid);
 }
 
+std::vector<float> g_window;
+int g_window_mode = 2, g_window_form = 0;
+// taper window of the following calls: n weights (n == 0 or w == NULL: none); mode = FftKernel's WIN (1 / 2);
+// form 0 = decided from the window's spectrum as fsea_plan_set_window does, 2 = the offset-binary form forced
+extern "C" void emu_set_window(const float *w, int n, int mode, int form) {
+    g_window.assign(w ? w : nullptr, w ? w + n : nullptr);
+    g_window_mode = mode;
+    g_window_form = form;
+}
+
 static double g_rot_delta = 0.0, g_rot_phase0 = 0.0;
 
 // in_kind 2 (frequency-shifted u8 input) takes its shift from here
@@ -84,7 +94,8 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.trace = nullptr;
     // the compile-time-mode kernels (MAG, DB5, DB10) serve raw int8 input (flip)
     const bool has_fixed = mode == fsea::MODE_MAG || mode == fsea::MODE_DB5_U8_DCFIX || mode == fsea::MODE_DB10_U8;
-    const int mt = (specialised && has_fixed && in_kind == fsea::IN_U8 && flip) ? mode : -1;
+    int mt = (specialised && has_fixed && in_kind == fsea::IN_U8 && flip) ? mode : -1;
+    if (!g_window.empty() && mt != fsea::MODE_MAG) mt = -1;  // the windowed kernels: compile-time MAG, or run-time mode
     const std::string v = variant ? variant : "";
     if (!v.empty()) {
         int rc = emu_variants_a(n, v, in_kind, mt, a, grid);

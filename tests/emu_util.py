@@ -55,10 +55,19 @@ def emu_lib():
 
 
 def emu_rows(iq, n, n_frames, hop=None, flip=True, mode=0, grid=2, specialised=True, in_kind=0, variant="",
-             shift=None, dynamic_units=True, run_len=None):
+             shift=None, dynamic_units=True, run_len=None, window=None, window_mode=2, window_form=0):
     """shift = (cycles_per_sample, phase0_cycles) selects the frequency-shifted u8 kernel (in_kind 2);
-    dynamic_units=False runs the multi-wave sizes with the static unit interleave (FftArgs::dynamic_units = 0)."""
+    dynamic_units=False runs the multi-wave sizes with the static unit interleave (FftArgs::dynamic_units = 0);
+    window = n float weights runs the windowed kernels (window_mode = FftKernel's WIN: 1 weights fetched per frame, 2
+    register-resident; window_form 2 forces the offset-binary form)."""
     hop = n if hop is None else hop
+    emu_lib().emu_set_window.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    if window is not None:
+        wf = np.ascontiguousarray(window, dtype=np.float32)
+        assert wf.size == n
+        emu_lib().emu_set_window(wf.ctypes.data, n, int(window_mode), int(window_form))
+    else:
+        emu_lib().emu_set_window(None, 0, 2, 0)
     if run_len is not None:                      # the half-overlap MAG kernel (hop == n / 2), runs of run_len frames
         in_kind = 3
         emu_lib().emu_set_run_len.argtypes = [ctypes.c_uint32]

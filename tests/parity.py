@@ -68,3 +68,15 @@ def check_mode_shifted(got, iq, n, n_frames, hop, flip, mode, cycles_per_sample,
         return check_db(got, want, O.rows_shifted(iq, n_frames, n, cycles_per_sample, phase0_cycles,
                                                   mode=O.MODE_MAG_NODC, **kw))
     return check_float(got, want)
+
+
+def check_mode_windowed(got, iq, n, n_frames, hop, flip, mode, window):
+    """check_mode for a plan with a taper window (oracle: orc_rows_windowed, x[j] = (-1)^j w[j] u8[j] / 256)."""
+    w = np.asarray(window, dtype=np.float32).astype(np.float64)   # the weights the kernel applies are the f32 values
+    kw = dict(hop=hop, flip=flip)
+    want = O.rows_windowed(iq, n_frames, n, w, mode=ORACLE_MODE[mode], **kw)
+    if mode in (1, 2):
+        return check_u8(got, want)
+    if mode == 5:
+        return check_db(got, want, O.rows_windowed(iq, n_frames, n, w, mode=O.MODE_MAG_NODC, **kw))
+    return check_float(got, want)

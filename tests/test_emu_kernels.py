@@ -281,3 +281,68 @@ def test_half_overlap_runs_keep_half_a_frame_in_registers(n, nf, grid, run_len):
     parity.check_mode(got, iq, n, nf, hop, True, 0)
     plain = emu_rows(iq, n, nf, hop=hop, grid=grid, dynamic_units=False)
     assert np.array_equal(got, plain)
+
+
+# ---- taper window (FftKernel<..., WIN>; fsea_plan_set_window) ----
+
+def _taper(name, n):
+    if name == "random":
+        return np.random.default_rng(n).uniform(-1.0, 2.0, n).astype(np.float32)
+    return O.window(name, n).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("wname,wmode", [("hann", 2), ("random", 1)])
+def test_windowed_kernels_all_sizes(n, wname, wmode):
+    """The windowed MAG kernel (weights register-resident / fetched per frame; centred form for the cosine-sum taper,
+    offset-binary form for the arbitrary one) against the oracle's windowed rows."""
+    nf = 21 if n <= 512 else (9 if n <= 2048 else 3)
+    iq = synth_iq(11 * n, 2 * nf * n)
+    w = _taper(wname, n)
+    got = emu_rows(iq, n, nf, window=w, window_mode=wmode, grid=2)
+    parity.check_mode_windowed(got, iq, n, nf, n, True, 0, w)
+
+
+@pytest.mark.parametrize("n", [32, 128, 1024, 4096])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+def test_windowed_run_time_mode_kernel(n, mode):
+    nf = 7 if n <= 1024 else 3
+    iq = synth_iq(400 + n + mode, 2 * nf * n)
+    for wname, flip, form in (("blackman", True, 0), ("random", False, 0), ("hann", False, 2)):
+        w = _taper(wname, n)
+        got = emu_rows(iq, n, nf, flip=flip, mode=mode, window=w, window_mode=1 + (mode & 1), window_form=form)
+        parity.check_mode_windowed(got, iq, n, nf, n, flip, mode, w)
+
+
+@pytest.mark.parametrize("n", [64, 512, 2048, 8192])
+def test_unit_window_gives_the_unwindowed_kernels_bits(n):
+    nf = 5 if n <= 2048 else 2
+    iq = synth_iq(77 + n, 2 * nf * n)
+    ones = np.ones(n, np.float32)
+    for mode, spec in ((0, True), (1, False), (3, False)):
+        base = emu_rows(iq, n, nf, mode=mode, specialised=spec)
+        for wmode in (1, 2):
+            got = emu_rows(iq, n, nf, mode=mode, specialised=spec, window=ones, window_mode=wmode)
+            assert np.array_equal(base.view(np.uint8), got.view(np.uint8)), (n, mode, wmode)
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_windowed_half_overlap_kernel(n):
+    hop, nf = n // 2, 7
+    iq = synth_iq(n + 5, 2 * ((nf - 1) * hop + n))
+    w = _taper("hann", n)
+    got = emu_rows(iq, n, nf, hop=hop, run_len=3, window=w, window_mode=2, grid=2)
+    parity.check_mode_windowed(got, iq, n, nf, hop, True, 0, w)
+
+
+def test_window_tables_decide_the_form():
+    """build_window_tables (fsea_tables.h, through the emulated launch): cosine-sum tapers qualify for the centred form --
+    then forcing the offset-binary form gives the same rows within tolerance, not the same bits."""
+    n, nf = 256, 4
+    iq = synth_iq(9, 2 * nf * n)
+    w = _taper("flattop", n)
+    a = emu_rows(iq, n, nf, mode=3, window=w)
+    b = emu_rows(iq, n, nf, mode=3, window=w, window_form=2)
+    assert not np.array_equal(a, b)
+    parity.check_mode_windowed(a, iq, n, nf, n, True, 3, w)
+    parity.check_mode_windowed(b, iq, n, nf, n, True, 3, w)

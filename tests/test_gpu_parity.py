@@ -11,7 +11,7 @@ import pytest
 from frequensea_amd import fsea, nrf
 from oracle import oracle as O
 from tests import parity
-from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, ROOT, synth_iq
+from tests.conftest import ALL_CAPTURE_KEYS, GOLDEN_KEYS, GOLDEN_SIZES, ROOT, synth_iq
 
 pytestmark = pytest.mark.gpu
 
@@ -163,6 +163,51 @@ def test_recorded_captures_match_golden(golden, key, n):
         else:
             parity.check_u8(got, want)
         plan.close()
+
+
+@pytest.mark.parametrize("key", ALL_CAPTURE_KEYS)
+def test_every_recorded_capture_matches_golden(golden_all, key):
+    """BASELINE.json: "outputs match FFTW on the same rfdata/*.raw inputs" -- all 35 full-size captures of the reference's
+    rfdata/ (tests/golden/rfdata_all_golden.npz: scipy/pocketfft f64 rows), at the nrf_* size and the headline size."""
+    raw = golden_all[key + "__raw"]
+    for n in (1024, 8192):
+        plan = fsea.Plan(n)
+        got = plan.exec_host(raw, 1)[0]
+        parity.check_float(got, golden_all["%s__mag_%d" % (key, n)])
+        plan.close()
+
+
+def test_whole_block_of_one_capture_through_the_batched_entry_and_the_nrf_api(golden_all, tmp_path):
+    """One 262144-byte block of a recorded capture (one libhackrf transfer): its 128 consecutive 1024-point frames in one
+    launch, and the same block through nrf_device_new (file replay) -> nrf_device_step -> nrf_fft_process ->
+    nrf_fft_get_buffer, which transforms the block's first 1024 samples per step (src/nrf.c:153-170, 598-631)."""
+    raw = golden_all["block__raw"]
+    want = golden_all["block__mag_1024"]
+    plan = fsea.Plan(1024)
+    got = plan.exec_host(raw, 128)
+    parity.check_float(got, want)
+    plan.close()
+    path = tmp_path / "block.raw"
+    raw.tofile(path)
+    L = nrf.nrf_lib()
+    dev = L.nrf_device_new(100.0, str(path).encode())   # no radio on the box: the file-replay device (src/nrf.c:309-318)
+    L.nrf_device_set_paused(dev, 1)
+    fft = L.nrf_fft_new(1024, 4)
+    import time
+    for _ in range(4):
+        L.nrf_device_step(dev)
+        time.sleep(0.06)                                    # > 2 replay periods of 1/60 s (the receive thread's pace)
+        buf = L.nrf_device_get_samples_buffer(dev)
+        assert np.array_equal(nrf.buffer_to_numpy(L, buf), O.flip_u8(raw))   # the byte flip of src/nrf.c:100-109
+        L.nrf_fft_process(fft, buf)
+        L.nut_buffer_free(buf)
+    out = L.nrf_fft_get_buffer(fft)
+    hist = nrf.buffer_to_numpy(L, out).reshape(4, 1024)
+    L.nut_buffer_free(out)
+    for r in range(4):
+        parity.check_float(hist[r], want[0])
+    L.nrf_fft_free(fft)
+    L.nrf_device_free(dev)
 
 
 def test_survey_known_answers_on_gpu(golden):

@@ -1,0 +1,247 @@
+"""GPU tier (-m gpu): the taper window fused into the kernels' byte conversion (fsea_plan_set_window; BASELINE.json's
+"fused unpack+window prologue", config 5's STFT) against the oracle's windowed rows -- the reference's unpack loop
+(src/nrf.c:601-614) with w[n] beside its (-1)^n.  Tolerances: tests/parity.py."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from frequensea_amd import fsea
+from oracle import oracle as O
+from tests import parity
+from tests.conftest import GOLDEN_KEYS, ROOT, synth_iq
+from tests.test_gpu_parity import SIZES, DeviceBuffer, units_policy  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _window(name, n, seed=0):
+    if name == "random":
+        return np.random.default_rng(seed + n).uniform(-1.0, 2.0, n).astype(np.float32)
+    if name == "ones":
+        return np.ones(n, np.float32)
+    if name == "kaiser":
+        from scipy.signal import get_window
+        return get_window(("kaiser", 8.6), n).astype(np.float32)
+    return fsea.window(name, n)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("wname", ["hann", "blackmanharris", "random"])
+def test_windowed_mag_rows_all_sizes(n, wname):
+    nf = 300 if n <= 1024 else 37
+    iq = synth_iq(7 * n + len(wname), 2 * nf * n)
+    w = _window(wname, n)
+    plan = fsea.Plan(n)
+    plan.set_window(w)
+    assert plan.window_form == (2 if wname == "random" else 1)
+    assert plan.kernel_name == "fsea_fft%d_u8_mag_win" % n
+    got = plan.exec_host(iq, nf)
+    parity.check_mode_windowed(got, iq, n, nf, n, True, 0, w)
+    assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
+    plan.close()
+
+
+@pytest.mark.parametrize("n", [32, 64, 256, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("wname", ["hann", "random"])
+def test_windowed_other_modes_and_byte_conventions(n, mode, wname):
+    nf = 33
+    iq = synth_iq(2000 + n + mode, 2 * nf * n)
+    w = _window(wname, n, seed=mode)
+    plan = fsea.Plan(n, mode=mode)
+    plan.set_window(w)
+    assert plan.kernel_name == "fsea_fft%d_u8_win" % n
+    for flip in (True, False):
+        got = plan.exec_host(iq, nf, flip=flip)
+        parity.check_mode_windowed(got, iq, n, nf, n, flip, mode, w)
+    plan.close()
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_a_window_of_ones_gives_the_unwindowed_kernels_bits(n):
+    """w == 1 is the reference itself: the windowed kernels (multiply by 1.0, DC term restored from the table) must give
+    bit for bit what the un-windowed kernels give, in every mode."""
+    nf = 64 if n <= 1024 else 17
+    iq = synth_iq(31 * n, 2 * nf * n)
+    for mode in (0, 1, 2, 3, 4, 5):
+        plan = fsea.Plan(n, mode=mode)
+        base = plan.exec_host(iq, nf)
+        name = plan.kernel_name
+        plan.set_window(np.ones(n, np.float32))
+        assert plan.window_form == 1 and plan.kernel_name.endswith("_win")
+        got = plan.exec_host(iq, nf)
+        assert np.array_equal(base.view(np.uint8), got.view(np.uint8)), (n, mode)
+        plan.set_window(None)                      # and the window can be taken off again
+        assert plan.window_form == 0 and plan.kernel_name == name
+        assert np.array_equal(base.view(np.uint8), plan.exec_host(iq, nf).view(np.uint8))
+        plan.close()
+
+
+def test_window_fill_matches_scipy_and_the_oracle():
+    from scipy.signal import get_window
+    for name in ("hann", "hamming", "blackman", "blackmanharris", "flattop"):
+        for n in (32, 1024, 16384):
+            w = fsea.window(name, n)
+            assert np.allclose(w, get_window(name, n), rtol=0, atol=1e-7), name
+            assert np.array_equal(w, O.window(name, n).astype(np.float32)), name
+    assert np.array_equal(fsea.window("rect", 64), np.ones(64, np.float32))
+
+
+def test_window_forms():
+    """Cosine-sum tapers take the centred form (DC term restored from its spectrum around bin n/2); a taper whose spectrum
+    is not confined to that band takes the offset-binary form; both inside the tolerance."""
+    n, nf = 4096, 24
+    iq = synth_iq(99, 2 * nf * n)
+    plan = fsea.Plan(n)
+    for name, form in (("hann", 1), ("hamming", 1), ("blackman", 1), ("flattop", 1), ("kaiser", 2), ("random", 2)):
+        w = _window(name, n)
+        plan.set_window(w)
+        assert plan.window_form == form, name
+        parity.check_mode_windowed(plan.exec_host(iq, nf), iq, n, nf, n, True, 0, w)
+    plan.close()
+
+
+def test_centred_form_keeps_weak_signals_accurate():
+    """What the centred form is for: with a signal far below the offset-binary DC term (sigma 1.5 LSB) the error stays
+    relative to the signal, not to the DC term."""
+    n, nf = 8192, 16
+    iq = synth_iq(5, 2 * nf * n, sigma=1.5, amp=3.0)
+    w = fsea.window("hann", n)
+    plan = fsea.Plan(n, mode=fsea.MODE_COMPLEX_F32)
+    plan.set_window(w)
+    got = plan.exec_host(iq, nf).astype(np.complex128)
+    want = O.rows_windowed(iq, nf, n, w.astype(np.float64), mode=O.MODE_COMPLEX)
+    keep = np.ones(n, bool)
+    keep[n // 2 - 2: n // 2 + 3] = False            # everything but the DC term's five bins
+    rel = np.linalg.norm((got - want)[:, keep]) / np.linalg.norm(want[:, keep])
+    assert rel <= 1e-6, rel
+    plan.close()
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_windowed_half_overlap_kernel(n, monkeypatch):
+    """hop == n/2 with a window: the half-overlap kernel (every sample loaded once) against the oracle, and bit for bit
+    against the ordinary windowed kernel."""
+    hop, nf = n // 2, 301
+    iq = synth_iq(n + 1, 2 * ((nf - 1) * hop + n))
+    w = fsea.window("hann", n)
+    plan = fsea.Plan(n, hop=hop)
+    plan.set_window(w)
+    assert plan.kernel_name == "fsea_fft%d_u8_mag_half_win" % n
+    got = plan.exec_host(iq, nf)
+    rows = np.r_[0:12, nf - 12:nf]
+    for f in rows:
+        parity.check_mode_windowed(got[f:f + 1], iq[2 * f * hop: 2 * (f * hop + n)], n, 1, n, True, 0, w)
+    plan.close()
+    monkeypatch.setenv("FSEA_NO_HALF_OVERLAP", "1")
+    plain = fsea.Plan(n, hop=hop)
+    plain.set_window(w)
+    assert plain.kernel_name == "fsea_fft%d_u8_mag_win" % n
+    assert np.array_equal(plain.exec_host(iq, nf), got)
+    plain.close()
+
+
+def test_config5_stft_with_hann_at_full_size():
+    """BASELINE.json config 5 with the taper north_star names: 16384-point frames at hop 8192 over a 2^26-sample stream
+    (8191 frames, device-resident), Hann.  Sampled rows against the oracle; the tone where it belongs in every row."""
+    n, hop, nf = 16384, 8192, 8191
+    n_samples = (nf - 1) * hop + n
+    rng = np.random.default_rng(55)
+    block = synth_iq(55, 2 * (1 << 20))
+    reps = (2 * n_samples + block.size - 1) // block.size
+    iq = np.tile(block, reps)[:2 * n_samples].copy()
+    iq[::4097] ^= rng.integers(0, 8, iq[::4097].size).astype(np.uint8)   # the tiled blocks are not identical
+    w = fsea.window("hann", n)
+    plan = fsea.Plan(n, hop=hop)
+    plan.set_window(w)
+    d_in, d_out = DeviceBuffer(iq.nbytes).upload(iq), DeviceBuffer(nf * n * 4)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    got = d_out.download(np.float32, (nf, n))
+    for f in (0, 1, 7, 8, 9, 4095, 4096, nf - 2, nf - 1):
+        parity.check_mode_windowed(got[f:f + 1], iq[2 * f * hop: 2 * (f * hop + n)], n, 1, n, True, 0, w)
+    peak = np.argmax(got, axis=1)
+    tone = n // 2 + n // 8
+    dc_bins = {n // 2 - 1, n // 2, n // 2 + 1}
+    assert all(int(p) == tone or int(p) in dc_bins for p in peak)
+    d_in.free()
+    d_out.free()
+    plan.close()
+
+
+@pytest.mark.parametrize("n", [1024, 4096, 8192])
+def test_windowed_long_launches_both_unit_distributions(n, units_policy):  # noqa: F811
+    nf = 4096 if n >= 4096 else 8192
+    iq = synth_iq(n * 3, 2 * nf * n)
+    w = _window("blackman", n)
+    plan = fsea.Plan(n)
+    plan.set_window(w)
+    d_in, d_out = DeviceBuffer(iq.nbytes).upload(iq), DeviceBuffer(nf * n * 4)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    got = d_out.download(np.float32, (nf, n))
+    for f in np.r_[0:6, nf // 2:nf // 2 + 4, nf - 6:nf]:
+        parity.check_mode_windowed(got[f:f + 1], iq[2 * f * n: 2 * (f + 1) * n], n, 1, n, True, 0, w)
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)           # identical launches give identical rows
+    plan.synchronize()
+    assert np.array_equal(got, d_out.download(np.float32, (nf, n)))
+    d_in.free()
+    d_out.free()
+    plan.close()
+
+
+def test_windowed_tiles_equal_windowed_rows():
+    n, tile_rows, n_tiles = 256, 64, 5
+    nf = tile_rows * n_tiles
+    iq = synth_iq(12, 2 * nf * n)
+    w = fsea.window("hann", n)
+    plan = fsea.Plan(n, mode=fsea.MODE_DB5_U8_DCFIX)
+    plan.set_window(w)
+    rows = plan.exec_host(iq, nf)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    width = n * n_tiles + 64
+    image = np.zeros((tile_rows, width), np.uint8)
+    d_img = DeviceBuffer(image.nbytes).upload(image)
+    plan.exec_tiled_device(d_in.ptr, nf, d_img.ptr, tile_rows, width, 32, tile_rows, n)
+    plan.synchronize()
+    image = d_img.download(np.uint8, image.shape)
+    for k in range(n_tiles):
+        assert np.array_equal(image[:, 32 + k * n: 32 + (k + 1) * n], rows[k * tile_rows:(k + 1) * tile_rows])
+    d_in.free()
+    d_img.free()
+    plan.close()
+
+
+def test_window_errors():
+    plan = fsea.Plan(1024)
+    bad = np.ones(1024, np.float32)
+    bad[17] = np.nan
+    with pytest.raises(fsea.FseaError, match="not finite"):
+        plan.set_window(bad)
+    plan.set_window("hann")
+    iq = synth_iq(1, 2 * 4 * 1024)
+    with pytest.raises(fsea.FseaError, match="taper window"):
+        plan.exec_shifted_host(iq, 4, 0.01)
+    with pytest.raises(fsea.FseaError, match="taper window"):
+        plan.exec_host_f64(np.zeros(2 * 4 * 1024), 4)
+    plan.set_window(None)
+    plan.exec_shifted_host(iq, 4, 0.01)
+    plan.close()
+    odd = fsea.Plan(1000, hop=1000)
+    with pytest.raises(fsea.FseaError, match="no kernel of its own"):
+        odd.set_window(np.ones(1000, np.float32))
+    odd.close()
+
+
+@pytest.mark.parametrize("key", GOLDEN_KEYS)
+@pytest.mark.parametrize("n", [1024, 8192, 16384])
+def test_recorded_captures_with_hann_match_golden(golden, key, n):
+    """Hann-windowed rows of the reference's recorded captures against the committed scipy rows (tests/golden/make_golden.py:
+    scipy.signal.get_window("hann", n) rounded to f32, scipy.fft in f64)."""
+    plan = fsea.Plan(n)
+    plan.set_window("hann")
+    got = plan.exec_host(golden[key + "__raw"], 1)[0]
+    parity.check_float(got, golden["%s__hann_mag_%d" % (key, n)])
+    plan.close()

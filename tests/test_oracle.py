@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.conftest import GOLDEN_KEYS, GOLDEN_SIZES, ROOT, synth_iq
+from tests.conftest import ALL_CAPTURE_KEYS, GOLDEN_KEYS, GOLDEN_SIZES, ROOT, synth_iq
 
 
 def test_flip_identity_all_bytes():
@@ -54,6 +54,66 @@ def test_rows_match_golden(golden, key, n):
         gotp = O.rows(raw, 1, n, mode=mode)[0]
         diff = np.abs(gotp.astype(int) - wantp.astype(int))
         assert diff.max() <= 1 and np.count_nonzero(diff) <= max(1, n // 1000)
+
+
+@pytest.mark.parametrize("key", ALL_CAPTURE_KEYS)
+def test_rows_of_every_recorded_capture_match_golden(golden_all, key):
+    """All 35 full-size captures of the reference's rfdata/ ("the same rfdata/*.raw inputs", BASELINE.json)."""
+    raw = golden_all[key + "__raw"]
+    for n in (1024, 8192):
+        want = golden_all["%s__mag_%d" % (key, n)]
+        got = O.rows(raw, 1, n)[0]
+        assert np.max(np.abs(got - want)) <= 1e-11 * max(1.0, want.max())
+
+
+def test_all_35_full_size_captures_are_in_the_fixture(golden_all):
+    assert len(ALL_CAPTURE_KEYS) == 35 and "rf_433p000_short" not in ALL_CAPTURE_KEYS
+    assert all(golden_all[k + "__raw"].size == 2 * 8192 for k in ALL_CAPTURE_KEYS)
+
+
+def test_whole_block_of_one_capture_matches_golden(golden_all):
+    """The 128 consecutive 1024-point frames of one 262144-byte block (one libhackrf transfer, c/fft-batch.c:54)."""
+    raw = golden_all["block__raw"]
+    assert raw.size == 262144
+    got = O.rows(raw, 128, 1024)
+    want = golden_all["block__mag_1024"]
+    assert np.max(np.abs(got - want)) <= 1e-11 * want.max()
+
+
+@pytest.mark.parametrize("key", GOLDEN_KEYS)
+@pytest.mark.parametrize("n", [1024, 8192, 16384])
+def test_hann_rows_match_golden(golden, key, n):
+    """The windowed oracle (orc_rows_windowed, orc_window_fill) against scipy's window and scipy's FFT."""
+    raw = golden[key + "__raw"]
+    w = O.window("hann", n).astype(np.float32).astype(np.float64)
+    got = O.rows_windowed(raw, 1, n, w)[0]
+    want = golden["%s__hann_mag_%d" % (key, n)]
+    assert np.max(np.abs(got - want)) <= 1e-11 * max(1.0, want.max())
+
+
+def test_oracle_windows_are_scipys():
+    from scipy.signal import get_window
+    for name in ("hann", "hamming", "blackman", "blackmanharris", "flattop"):
+        for n in (32, 1000, 1024, 16384):
+            assert np.max(np.abs(O.window(name, n) - get_window(name, n))) <= 1e-14, name
+    assert np.array_equal(O.window("rect", 64), np.ones(64))
+
+
+def test_windowed_oracle_is_the_plain_one_for_unit_weights_and_linear_in_the_window():
+    rng = np.random.default_rng(3)
+    n, nf = 512, 3
+    raw = rng.integers(0, 256, 2 * n * nf).astype(np.uint8)
+    for mode in (O.MODE_MAG, O.MODE_DB10_U8, O.MODE_DB5_U8_DCFIX, O.MODE_COMPLEX):
+        assert np.array_equal(O.rows_windowed(raw, nf, n, np.ones(n), mode=mode), O.rows(raw, nf, n, mode=mode))
+    w1, w2 = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    a = O.rows_windowed(raw, nf, n, w1, mode=O.MODE_COMPLEX)
+    b = O.rows_windowed(raw, nf, n, w2, mode=O.MODE_COMPLEX)
+    c = O.rows_windowed(raw, nf, n, 2 * w1 - 3 * w2, mode=O.MODE_COMPLEX)
+    assert np.max(np.abs(c - (2 * a - 3 * b))) <= 1e-9
+    # a Hann taper is the 3-tap stencil 0.5 X[k] - 0.25 X[k-1] - 0.25 X[k+1] of the rectangular spectrum
+    x = O.rows(raw, nf, n, mode=O.MODE_COMPLEX)
+    h = O.rows_windowed(raw, nf, n, O.window("hann", n), mode=O.MODE_COMPLEX)
+    assert np.max(np.abs(h - (0.5 * x - 0.25 * np.roll(x, 1, axis=1) - 0.25 * np.roll(x, -1, axis=1)))) <= 1e-9
 
 
 @pytest.mark.parametrize("key", GOLDEN_KEYS[:2])

@@ -14,6 +14,7 @@ from tests.conftest import ROOT
 LIB = os.path.join(ROOT, "frequensea_amd", "libfsea_hip.so")
 SIZES = (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384)
 KINDS = ("u8_mag", "u8_db5", "u8_db10", "u8", "u8_rot", "f32")
+WIN_KINDS = ("u8_mag_win", "u8_win")
 
 
 def _kernels(path):
@@ -63,19 +64,24 @@ def kernels():
 def test_every_size_has_its_six_entry_points_and_nothing_experimental(kernels):
     fft = sorted(k for k in kernels if k.startswith("fsea_fft"))
     # + the half-overlap MAG kernels of the two sizes with one frame per workgroup (hop == N/2: every sample loaded once)
-    assert fft == sorted(["fsea_fft%d_%s" % (n, kind) for n in SIZES for kind in KINDS] +
-                         ["fsea_fft8192_u8_mag_half", "fsea_fft16384_u8_mag_half"])
+    # + the windowed kernels (fsea_plan_set_window): MAG, run-time mode, and the half-overlap MAG kernels again
+    assert fft == sorted(["fsea_fft%d_%s" % (n, kind) for n in SIZES for kind in KINDS + WIN_KINDS] +
+                         ["fsea_fft%d_u8_mag_half%s" % (n, w) for n in (8192, 16384) for w in ("", "_win")])
     assert not [k for k in kernels if "abl" in k]
 
 
 def test_hot_kernels_do_not_spill(kernels):
-    for name in ("fsea_fft8192_u8_mag_half", "fsea_fft16384_u8_mag_half"):
+    for name in ["fsea_fft%d_u8_mag_half%s" % (n, w) for n in (8192, 16384) for w in ("", "_win")]:
         k = kernels[name]
         assert k[".vgpr_count"] <= 256 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, name
     for n in SIZES:
-        for kind in KINDS:
+        for kind in KINDS + WIN_KINDS:
             k = kernels["fsea_fft%d_%s" % (n, kind)]
             assert k[".vgpr_count"] <= 256 and k[".wavefront_size"] == 64
+            if (n, kind) == (1024, "u8_win"):
+                # the run-time-mode windowed kernel at 1024 points (four bins per lane, 32 weights in flight): 4 registers
+                assert k[".vgpr_spill_count"] <= 4 and k[".private_segment_fixed_size"] <= 32, (n, kind)
+                continue
             if kind == "f32":
                 # the f32-complex input branch (NUT_BUFFER_F64, one frame per call) prefetches 64 VGPRs of rows: a few
                 # spilled registers at two sizes are accepted there, not more
@@ -87,7 +93,7 @@ def test_hot_kernels_do_not_spill(kernels):
 def test_occupancy_budget_of_the_multi_wave_sizes(kernels):
     """Two workgroups per CU at 4096 and 8192 points (LDS <= 80 KB each, <= 256 VGPRs at 2 waves per SIMD), one at 16384."""
     for n, lds_max in ((4096, 80 * 1024), (8192, 80 * 1024), (16384, 160 * 1024)):
-        for kind in KINDS:
+        for kind in KINDS + WIN_KINDS:
             k = kernels["fsea_fft%d_%s" % (n, kind)]
             assert k[".group_segment_fixed_size"] <= lds_max, (n, kind)
     assert kernels["fsea_fft8192_u8_mag"][".max_flat_workgroup_size"] == 256
