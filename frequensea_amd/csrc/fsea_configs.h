@@ -26,36 +26,8 @@
 #define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 6328478
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 6328456
 
-// Windowed kernels (FftKernel<..., WIN>; fsea_plan_set_window): where the lane's P taper weights live.  2 = in registers
-// for the workgroup's lifetime, 1 = fetched again for every frame (from L2, in front of the previous frame's row stores) at
-// the sizes where 32 more resident registers would spill.
-#ifndef FSEA_WIN_32
-#define FSEA_WIN_32 2
-#endif
-#ifndef FSEA_WIN_64
-#define FSEA_WIN_64 2
-#endif
-#ifndef FSEA_WIN_128
-#define FSEA_WIN_128 2
-#endif
-#ifndef FSEA_WIN_256
-#define FSEA_WIN_256 2
-#endif
-#ifndef FSEA_WIN_512
-#define FSEA_WIN_512 2
-#endif
-#ifndef FSEA_WIN_1024
-#define FSEA_WIN_1024 1
-#endif
-#ifndef FSEA_WIN_2048
-#define FSEA_WIN_2048 1
-#endif
-#ifndef FSEA_WIN_4096
-#define FSEA_WIN_4096 1
-#endif
-#ifndef FSEA_WIN_8192
-#define FSEA_WIN_8192 2
-#endif
-#ifndef FSEA_WIN_16384
-#define FSEA_WIN_16384 2
-#endif
+// Windowed kernels (FftKernel<..., WIN>; fsea_plan_set_window): the lane's P taper weights stay in registers for the
+// workgroup's lifetime at every size (WIN = 2).  Fetching them again for every frame (WIN = 1, the tuning library's "w1"
+// variants) frees 32 registers between pass 0 and the last pass and loses 2-5 % to the extra loads
+// (profiles/r04_window_cost.txt).
+#define FSEA_WIN 2

@@ -142,6 +142,39 @@ __device__ __forceinline__ void dft_regs(cf *x) {
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
 
+// Pass 0 of a windowed kernel: the same DFT over x[0], x[S], ... of samples that still lack their taper weight; weight
+// e = E0 + i S of the lane (wv[e / 2], half e % 2; (-1)^n folded in) belongs to x[i S].  The first butterfly level takes the
+// weights along: (wa a) +- (wb b) = one packed multiply and two packed FMAs per pair, where weighting the samples first
+// costs two multiplies and two adds -- 3 packed ops per pair instead of 4 (2 without a window).  With unit weights the
+// results are the plain butterfly's bits: fma(a, 1, b) = a + b.
+template <int R, int S, int E0, int I = 0>
+__device__ __forceinline__ void dft_win_level(const cf *x, const cf *wv, cf *y) {
+    if constexpr (I < R / 2) {  // (template recursion: the weight's half is selected by `if constexpr`, no dead asm left behind)
+        constexpr int BITS = ilog2c(R), EA = E0 + I * S, EB = E0 + (I + R / 2) * S;
+        const cf a = x[I * S], b = x[(I + R / 2) * S];
+        cf t;
+        if constexpr (EB & 1) t = pk_scale_hi(b, wv[EB / 2]);
+        else t = pk_scale_lo(b, wv[EB / 2]);
+        if constexpr (EA & 1) {
+            y[bitrev_c(I, BITS)] = pk_wfma_hi(a, wv[EA / 2], t);
+            y[bitrev_c(I + R / 2, BITS)] = pk_wfms_hi(a, wv[EA / 2], t);
+        } else {
+            y[bitrev_c(I, BITS)] = pk_wfma_lo(a, wv[EA / 2], t);
+            y[bitrev_c(I + R / 2, BITS)] = pk_wfms_lo(a, wv[EA / 2], t);
+        }
+        dft_win_level<R, S, E0, I + 1>(x, wv, y);
+    }
+}
+template <int R, int S, int E0, bool MI = true>
+__device__ __forceinline__ void dft_regs_win(cf *x, const cf *wv) {
+    static_assert(R >= 2 && R <= 64 && (R & (R - 1)) == 0, "radix must be 2..64");
+    cf y[R];
+    dft_win_level<R, S, E0>(x, wv, y);
+    dft_const_levels<R, 2, MI>(y);
+#pragma unroll
+    for (int i = 0; i < R; ++i) x[i * S] = y[i];
+}
+
 // The same DFT with the inter-pass twiddle multiply x[i] *= tw[(i - 1) TS] (i >= 1) fused into
 // the first butterfly level, whose own twiddle is 1: with a = x[i] tw_i and b = x[i + R/2] tw_j,
 //   plus = a + b = pk_cmul_add(x[i + R/2], tw_j, a)   2 pk_fma
@@ -644,9 +677,10 @@ __device__ __forceinline__ cf turn_phasor_f32(double turns) {
 // RUNS: the 50 %-overlap form (hop == N/2, BASELINE.json's STFT configuration): a workgroup takes RUNS of consecutive
 // frames, and the second half of every frame's bytes -- pass-0 rows R0/2 .. R0-1 of each lane -- is kept in registers as
 // rows 0 .. R0/2-1 of the next frame, so that every sample is loaded once (FftArgs::run_len frames per run; static units).
-// WIN: the taper window fused into pass 0's conversion (fsea_plan_set_window; north_star's "fused unpack+window
-// prologue"): v = (u8 - 128) * ((-1)^n w[n]), one packed multiply per sample behind the byte conversion, the weights two
-// to a register pair as they were loaded.  1 = the lane's P weights are fetched again for every frame (one run of P
+// WIN: the taper window fused into pass 0 (fsea_plan_set_window; north_star's "fused unpack+window prologue"): the
+// samples x[n] = (u8 - 128) * ((-1)^n w[n]) are never formed -- the first butterfly level of pass 0 takes the weights
+// along (dft_regs_win: half a packed op per sample more than without a window), the weights two to a register pair as
+// they were loaded.  1 = the lane's P weights are fetched again for every frame (one run of P
 // floats per lane from a table that lives in L2; issued in front of the previous frame's row stores, so that they have
 // arrived when the frame's bytes are converted and hold registers only from there to there), 2 = they stay in registers
 // for the workgroup's lifetime.  The offset-binary DC term is put back behind the last pass from FftArgs::win_dc.
@@ -1171,13 +1205,19 @@ struct FftKernel {
             wv[2 * i + 1] = cf{u2f(q[2]), u2f(q[3])};
         }
     }
-    // pass 0's conversion with the weights applied: v[i] = byte value * weight i
+    // pass 0's conversion for the windowed kernels: the byte values as they are (centred, or offset-binary), no (-1)^n --
+    // weight and sign are applied by the first butterfly level (pass0_windowed)
     template <bool OFFSET>
-    static __device__ __forceinline__ void convert_windowed(const Raw *raw, uint32_t xormask, int t, const cf *wv, cf *v) {
+    static __device__ __forceinline__ void convert_windowed(const Raw *raw, uint32_t xormask, int t, cf *v) {
 #pragma unroll
         for (int r = 0; r < R0; ++r) convert_row<IN, C0, false, OFFSET>(raw[r], OFFSET ? xormask ^ 0x80808080u : xormask, C0 * t, v + r * C0);
-#pragma unroll
-        for (int i = 0; i < P; ++i) v[i] = (i & 1) ? pk_scale_hi(v[i], wv[i / 2]) : pk_scale_lo(v[i], wv[i / 2]);
+    }
+    template <int C = 0>
+    static __device__ __forceinline__ void pass0_windowed(cf *v, const cf *wv) {
+        if constexpr (C < C0) {
+            dft_regs_win<R0, C0, C, MI>(v + C, wv);
+            pass0_windowed<C + 1>(v, wv);
+        }
     }
 
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
@@ -1843,8 +1883,8 @@ struct FftKernel {
                     }
                 }
             } else if constexpr (WIN != 0) {
-                if (a.win_offset != 0) convert_windowed<true>(raw, xormask, t, wv, v);
-                else convert_windowed<false>(raw, xormask, t, wv, v);
+                if (a.win_offset != 0) convert_windowed<true>(raw, xormask, t, v);
+                else convert_windowed<false>(raw, xormask, t, v);
             } else {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], xormask, C0 * t, v + r * C0);
@@ -1854,8 +1894,12 @@ struct FftKernel {
                 asm volatile("" ::"v"(v[0]));
                 a.trace[32 * b + 30] = wall_clock64();
             }
+            if constexpr (WIN != 0) {
+                pass0_windowed(v, wv);
+            } else {
 #pragma unroll
-            for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0, MI>(v + c);
+                for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0, MI>(v + c);
+            }
             if constexpr (LAZY_SYNC) lazy_sync();  // the previous frame's last read is complete everywhere
             lds_write<0>(lds, v, t);
             frame_sync();

@@ -45,6 +45,29 @@ __device__ __forceinline__ cf pk_scale_hi(cf a, cf wp) {
     return t;
 }
 
+// a * (weight) + c and a * (weight) - c with the real weight broadcast from the low / high half of wp: the first butterfly
+// level of pass 0 with the taper folded in, (wa a) +- (wb b) as one packed multiply and two packed FMAs for the pair.
+__device__ __forceinline__ cf pk_wfma_lo(cf a, cf wp, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(wp), "v"(c));
+    return t;
+}
+__device__ __forceinline__ cf pk_wfma_hi(cf a, cf wp, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(t) : "v"(a), "v"(wp), "v"(c));
+    return t;
+}
+__device__ __forceinline__ cf pk_wfms_lo(cf a, cf wp, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(a), "v"(wp), "v"(c));
+    return t;
+}
+__device__ __forceinline__ cf pk_wfms_hi(cf a, cf wp, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(a), "v"(wp), "v"(c));
+    return t;
+}
+
 // c + a * w with the same two-instruction shape (the product's first half takes c as addend).
 __device__ __forceinline__ cf pk_cmul_add(cf a, cf w, cf c) {
     cf t;

@@ -1,5 +1,5 @@
 // Tuning library only: the windowed kernels with the taper weights fetched per frame ("w1") or register-resident ("w2"),
-// on the product configurations, for the A/B that chose fsea_configs.h's FSEA_WIN_<n> (profiles/r04_window_*.txt).
+// on the product configurations, for the A/B behind fsea_configs.h's FSEA_WIN (profiles/r04_window_cost.txt).
 #include "fsea_configs.h"
 #include "fsea_registry.h"
 #define FSEA_WIN_AB(N, CFG)                                                 \

@@ -16,6 +16,10 @@ static inline cf pk_cmul(cf a, cf w) {
 static inline cf pk_cmul_uniform(cf a, cf w) { return pk_cmul(a, w); }
 static inline cf pk_scale_lo(cf a, cf wp) { return cf{a[0] * wp[0], a[1] * wp[0]}; }
 static inline cf pk_scale_hi(cf a, cf wp) { return cf{a[0] * wp[1], a[1] * wp[1]}; }
+static inline cf pk_wfma_lo(cf a, cf wp, cf c) { return cf{fmaf(a[0], wp[0], c[0]), fmaf(a[1], wp[0], c[1])}; }
+static inline cf pk_wfma_hi(cf a, cf wp, cf c) { return cf{fmaf(a[0], wp[1], c[0]), fmaf(a[1], wp[1], c[1])}; }
+static inline cf pk_wfms_lo(cf a, cf wp, cf c) { return cf{fmaf(a[0], wp[0], -c[0]), fmaf(a[1], wp[0], -c[1])}; }
+static inline cf pk_wfms_hi(cf a, cf wp, cf c) { return cf{fmaf(a[0], wp[1], -c[0]), fmaf(a[1], wp[1], -c[1])}; }
 
 static inline cf pk_cmul_add(cf a, cf w, cf c) {
     cf t = cf{fmaf(a[0], w[0], c[0]), fmaf(a[1], w[0], c[1])};
