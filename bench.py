@@ -52,13 +52,20 @@ WORKLOADS = {
 }
 
 
-def numpy_rows(raw_u8, n_frames, n, hop, mode="mag"):
+EXTRA_REGIONS = 5   # timed regions per informational figure (median reported)
+
+
+def numpy_rows(raw_u8, n_frames, n, hop, mode="mag", window=None):
     """Sanity guard for what was just timed, numpy only (the parity tests proper live in tests/; the
     oracle is used by bench.py in the cpu_baseline leg alone): raw HackRF bytes -> offset binary ->
     x[k] = (-1)^k u8/256 -> forward FFT -> magnitude with bin N/2 := bin N/2-1 (src/nrf.c:599-630),
     or the *5 dB pixels with the same patch (c/fft-batch-broad.c:106-121)."""
     out = []
     sign = 1.0 - 2.0 * (np.arange(n) & 1)
+    if window:                                       # periodic cosine-sum taper beside the (-1)^n, rounded to f32 as the kernel's
+        coef = {"hann": (0.5, 0.5), "hamming": (0.54, 0.46), "blackman": (0.42, 0.5, 0.08)}[window]
+        w = sum((-1) ** k * a * np.cos(2 * np.pi * k * np.arange(n) / n) for k, a in enumerate(coef))
+        sign = sign * w.astype(np.float32).astype(np.float64)
     for f in range(n_frames):
         u = (raw_u8[2 * f * hop: 2 * (f * hop + n)] ^ np.uint8(0x80)).astype(np.float64) / 256.0
         spec = np.fft.fft((u[0::2] + 1j * u[1::2]) * sign)
@@ -88,7 +95,10 @@ def synth_batch(seed, n_bytes):
     return out.view(np.uint8)
 
 
-def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
+def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repeats=1, window=None):
+    """K = `steps` timed steps of `workload` behind `warmup` untimed ones.  repeats > 1 (the informational `extra` runs):
+    the timed region is measured that many times back to back and the MEDIAN region is reported, so that a 20-step region
+    of a side workload is not one sample of a cold clock.  window: a taper name for fsea_plan_set_window, or None."""
     from frequensea_amd import fsea
 
     n, frames, hop = WORKLOADS[workload]
@@ -97,6 +107,8 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
     if variant:
         fsea.use_tune_library()                                  # variants live in libfsea_hip_tune.so only
     plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_MAG_F32, device=dev.index, variant=variant)
+    if window:
+        plan.set_window(window)
     in_bytes = plan.in_bytes(frames)
     host = synth_batch(3 + 1000 * rank, in_bytes)
     ins, outs = [], []
@@ -126,22 +138,26 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(steps):
-        step(warmup + k)
-    ev1.record()
-    torch.cuda.synchronize()
-    # this rank's own K steps are done: its clock stops here; the closing barrier brackets the region, the
-    # job's time is the MAX over ranks (below), and a collective's own latency is not charged to the steps
-    t1 = time.perf_counter()
+    walls, kernels = [], []
+    for rep in range(max(1, repeats)):
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for k in range(steps):
+            step(warmup + rep * steps + k)
+        ev1.record()
+        torch.cuda.synchronize()
+        # this rank's own K steps are done: its clock stops here; the closing barrier brackets the region, the
+        # job's time is the MAX over ranks (below), and a collective's own latency is not charged to the steps
+        t1 = time.perf_counter()
+        walls.append(t1 - t0)
+        kernels.append(ev0.elapsed_time(ev1) / steps)  # events on the launch stream
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    wall = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / steps          # events on the launch stream
+    wall = float(np.median(walls))
+    kernel_ms = float(np.median(kernels))
     if dist is not None:
         tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -156,12 +172,15 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
             s = k % sets
             plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=streams[k % 2].cuda_stream)
         torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for k in range(steps):
-            s = k % sets
-            plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=streams[k % 2].cuda_stream)
-        torch.cuda.synchronize()
-        two_stream = frames * steps / (time.perf_counter() - t2)
+        rates = []
+        for rep in range(max(1, repeats)):
+            t2 = time.perf_counter()
+            for k in range(steps):
+                s = k % sets
+                plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=streams[k % 2].cuda_stream)
+            torch.cuda.synchronize()
+            rates.append(frames * steps / (time.perf_counter() - t2))
+        two_stream = float(np.median(rates))
         plan.exec_device(ins[0].data_ptr(), frames, outs[0].data_ptr(), flip=True, stream=stream)
         torch.cuda.synchronize()
     sample = outs[0][: 4 * n].cpu().numpy().reshape(4, n)
@@ -169,10 +188,10 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets):
     grid = plan.grid(frames)
     plan.close()
     return dict(n=n, frames=frames, hop=hop, wall=wall, kernel_ms=kernel_ms, kernel=kname, grid=grid, two_stream=two_stream,
-                sample=sample, host_head=np.roll(host, 0)[: 2 * 4 * hop + 2 * n])
+                sample=sample, host_head=np.roll(host, 0)[: 2 * 4 * hop + 2 * n], steps=steps)
 
 
-def run_broad(args, rank, world, dist, torch, steps, warmup):
+def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     """the fft-batch-broad sweep -- 512 centre frequencies x 256 frames x 4096-pt,
     u8 dB tiles (DB5 + DC fix), centre frequencies sharded over the ranks, tiles gathered to rank 0 over
     RCCL chunk by chunk (overlapped with the next chunk's FFT) and max-composited into the stitched image
@@ -248,27 +267,72 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
     for _ in range(max(warmup, 1)):
         img = step()
     torch.cuda.synchronize()
+    # clock pre-warm, as for the headline workload (untimed; config.clock_prewarm_s)
+    t_pre = time.perf_counter()
+    while world == 1 and time.perf_counter() - t_pre < args.prewarm:
+        for _ in range(8):
+            img = step()
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        img = step()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0       # own completion (rank 0: everything gathered); MAX over ranks below
+    walls, issues = [], []
+    for rep in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            img = step()
+        t_issued = time.perf_counter()    # the host has handed over all K steps (they run asynchronously behind it)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        issues.append(t_issued - t0)
+    wall = float(np.median(walls))        # own completion (rank 0: everything gathered); MAX over ranks below
+    host_issue_ms = 1e3 * float(np.median(issues)) / steps
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    # FFT kernel alone on this rank's shard (HIP events on the launch stream)
+    # FFT kernel alone on this rank's shard (HIP events on the launch stream), in the step's own form: rank 0's tiles
+    # written into the stitched image
     if ingest:
         iq.copy_(host_iq)
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record()
-    for _ in range(10):
-        plan.exec_device(iq.data_ptr(), (hi - lo) * rows, px.data_ptr(), flip=True, stream=stream)
-    k1.record()
-    torch.cuda.synchronize()
-    kernel_ms = k0.elapsed_time(k1) / 10
+    kms = []
+    for rep in range(max(3, repeats)):
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for _ in range(10):
+            if rank == 0 and not args.no_fused_stitch:
+                plan.exec_tiled_device(iq.data_ptr(), (hi - lo) * rows, img.data_ptr(), img.shape[0], img.shape[1], lo * n,
+                                       rows, n, flip=True, stream=stream)
+            else:
+                plan.exec_device(iq.data_ptr(), (hi - lo) * rows, px.data_ptr(), flip=True, stream=stream)
+        k1.record()
+        torch.cuda.synchronize()
+        kms.append(k0.elapsed_time(k1) / 10)
+    kernel_ms = float(np.median(kms))
+    # one GPU, resident captures: consecutive sweeps issued alternately on two streams, each with its own image -- one
+    # launch's drain under the next one's ramp, what a double-buffered consumer of independent sweeps gets
+    two_stream_ms = None
+    if world == 1 and not ingest and not args.no_fused_stitch:
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        images = [img, torch.empty_like(img)]
+        torch.cuda.synchronize()
+
+        def sweep_on(k):
+            plan.exec_tiled_device(iq.data_ptr(), tiles * rows, images[k % 2].data_ptr(), img.shape[0], img.shape[1], 0, rows, n,
+                                   flip=True, stream=streams[k % 2].cuda_stream)
+        for k in range(8):
+            sweep_on(k)
+        torch.cuda.synchronize()
+        ts = []
+        for rep in range(max(3, repeats)):
+            t2 = time.perf_counter()
+            for k in range(steps):
+                sweep_on(k)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t2) / steps)
+        two_stream_ms = 1e3 * float(np.median(ts))
+        if not torch.equal(images[0], images[1]):
+            raise SystemExit("bench broad: the two streams' stitched images differ")
+        del images
     if dist is not None:
         tt = torch.tensor([wall, kernel_ms], dtype=torch.float64,
                           device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -300,12 +364,17 @@ def run_broad(args, rank, world, dist, torch, steps, warmup):
                                 "written in place by the FFT kernel (fsea_exec_u8_tiled_device), received ones copied in"),
                    "regime": ("ingest: captures start in pinned host memory, H2D inside the step (one PCIe link per GPU)"
                               if ingest else "resident: captures in HBM when the step starts (gather is xGMI-link-bound)"),
-                   "gather_chunks": n_chunks,
+                   "gather_chunks": n_chunks, "clock_prewarm_s": args.prewarm if world == 1 else 0.0,
                    "parallelism": "centre frequencies sharded x%d, u8 tiles gathered by grouped send/recv" % world},
         "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": plan.kernel_name, "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg},
         "stitched_pixel_max_diff_vs_numpy_guard": check,
+        # the step by its own clock and by the FFT kernel's: the difference is what the host spends per step that is not
+        # hidden behind the device (first submission and last synchronise of the K-step region, spread over K)
+        "ms_per_step_kernel_events": kernel_ms, "host_issue_ms_per_step": host_issue_ms,
+        "roofline_frac_by_step_time": alg / (1e-3 * wall / steps) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
+        "ms_per_step_two_streams": two_stream_ms, "timed_regions": max(1, repeats),
     }
     plan.close()
     return line
@@ -473,6 +542,67 @@ def cpu_nrf_stream(O, n=1024, h=1024, frames=40):
                     "here; its powf(-1, ii) per sample is a sign select in the restatement, so the reference itself is slower)" % (n, h)}
 
 
+def energy_per_frame(torch, n=8192, frames=16384, seconds=1.6):
+    """Joules per frame of the headline kernel, rectangular and with a Hann taper: package power (rocm-smi, sampled while
+    the kernel runs back to back on noise-like input) x HIP-event launch time / frames.  {} when rocm-smi cannot be read."""
+    import re
+    import subprocess
+    import threading
+    from frequensea_amd import fsea
+    smi = "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return {}
+
+    def power():
+        try:
+            out = subprocess.run([smi, "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            m = re.search(r"Package Power \(W\):\s*([0-9.]+)", out)
+            return float(m.group(1)) if m else None
+        except Exception:
+            return None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    host = synth_batch(9, 2 * n * frames)
+    d_in = torch.from_numpy(host).to(dev)
+    d_out = torch.empty(frames * n, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for tag, window in (("rect", None), ("hann", "hann")):
+        plan = fsea.Plan(n, device=dev.index)
+        if window:
+            plan.set_window(window)
+        watts, stop = [], []
+
+        def sampler():
+            time.sleep(0.5)                                # clocks and power settle
+            while not stop:
+                p = power()
+                if p is not None:
+                    watts.append(p)
+                time.sleep(0.15)
+        th = threading.Thread(target=sampler)
+        th.start()
+        ms = []
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                plan.exec_device(d_in.data_ptr(), frames, d_out.data_ptr(), flip=True, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / 20)
+        stop.append(1)
+        th.join()
+        plan.close()
+        if not watts:
+            return {}
+        w, t = float(np.median(watts)), float(np.median(ms[len(ms) // 3:]))
+        res["energy_uj_per_frame_n8192_" + tag] = w * t * 1e-3 / frames * 1e6
+        res["package_power_w_n8192_" + tag] = w
+    res["energy_note"] = "rocm-smi package power x HIP-event launch time / frames, %d-frame launches back to back for %.1f s" % (frames, seconds)
+    return res
+
+
 def skeleton_rates():
     import subprocess
     script = os.path.join(ROOT, "scripts", "skeleton_rates.py")
@@ -581,6 +711,8 @@ def main():
                     help="broad: rank 0 stitches its own tiles with the composite kernel instead of writing them in place")
     ap.add_argument("--prewarm", type=float, default=0.25,
                     help="seconds of untimed steps in front of the --warmup steps (clock settling); 0 = none")
+    ap.add_argument("--window", default=None, choices=["hann", "hamming", "blackman"],
+                    help="taper fused into pass 0 (fsea_plan_set_window); default: none = the reference's rectangular frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--two-stream", action="store_true",
@@ -629,15 +761,16 @@ def main():
             dist.destroy_process_group()
         return
 
-    res = run_gpu(args, args.workload, rank, world, dist, torch, args.steps, args.warmup, args.sets)
+    res = run_gpu(args, args.workload, rank, world, dist, torch, args.steps, args.warmup, args.sets, window=args.window)
     n, frames, hop = res["n"], res["frames"], res["hop"]
-    # The timed region is the K steps between the opening and the closing synchronisation.  Its length is taken from the
-    # two HIP events recorded on the launch stream in front of the first and behind the last of those K steps (SURVEY.md
-    # 8(d): hipEvent timing; MAX over ranks), which is the time the device spent on them; the host's wall clock around the
-    # same region, which adds the submission latency of the first launch and the return latency of the last
-    # synchronisation (2-3 us per step at K = 20), is reported beside it as value_wall / ms_per_step_wall.
-    value = world * frames / (res["kernel_ms"] * 1e-3)
-    value_wall = world * frames * args.steps / res["wall"]
+    # The timed region is the K steps between the opening and the closing barrier + device synchronise; `value` and
+    # `ms_per_step` are the HOST WALL CLOCK of that region (MAX over ranks), as the bench contract defines them and as every
+    # BENCH_r0x line before round 3 did (round 3 took them from the HIP events instead, which reads 3-5 % higher at K = 20:
+    # first-launch submission and final-synchronise latency fall away).  The two HIP events recorded on the
+    # launch stream around the same K steps give the device's own time for them: `value_events` / `ms_per_step_events`,
+    # and -- being the kernel's average launch duration -- the roofline figures.
+    value = world * frames * args.steps / res["wall"]
+    value_events = world * frames / (res["kernel_ms"] * 1e-3)
     alg_bytes = (2 * hop + 4 * n) * frames                      # 2*hop read + 4*N written
     achieved = alg_bytes / (res["kernel_ms"] * 1e-3) / 1e9
     line = {
@@ -647,24 +780,28 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": res["kernel_ms"],
+        "ms_per_step": 1e3 * res["wall"] / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "msamples_per_sec": value * hop / 1e6,
-        "timing": "HIP events on the launch stream around the K timed steps, MAX over ranks; host wall clock of the same region in *_wall",
-        "value_wall": value_wall,
-        "ms_per_step_wall": 1e3 * res["wall"] / args.steps,
+        "timing": "value / ms_per_step: host wall clock of the K timed steps between barrier + synchronise on both sides, MAX "
+                  "over ranks; *_events: the two HIP events on the launch stream around the same K steps (device time)",
+        "value_events": value_events,
+        "ms_per_step_events": res["kernel_ms"],
         "config": {"workload": "%s: batched %d-pt FFT, %d frames per GPU per step, int8 IQ resident in HBM, "
-                               "MAG_F32 epilogue (nrf_fft_process semantics)" % (args.workload, n, frames),
-                   "fft_size": n, "frames_per_step_per_gpu": frames, "hop": hop,
+                               "MAG_F32 epilogue (nrf_fft_process semantics)%s" %
+                               (args.workload, n, frames, ", %s taper fused into pass 0" % args.window if args.window else ""),
+                   "fft_size": n, "frames_per_step_per_gpu": frames, "hop": hop, "window": args.window or "rectangular (the reference)",
                    "buffer_sets": args.sets, "clock_prewarm_s": args.prewarm,
                    "parallelism": "frames sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": res["kernel"], "avg_launch_ms": res["kernel_ms"],
+                     "avg_launch_ms_source": "HIP events on the launch stream over the K timed steps",
+                     "frac_by_step_time": alg_bytes / (res["wall"] / args.steps) / 1e9 / HBM_PEAK_GBPS,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "read_only_frac": (2 * hop * frames) / (res["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "grid_block_lds": list(res["grid"])},
@@ -684,16 +821,21 @@ def main():
 
     if rank == 0:
         # correctness guard on what was just timed
-        want = numpy_rows(res["host_head"], 4, n, hop)
+        want = numpy_rows(res["host_head"], 4, n, hop, window=args.window)
         rel = float(np.linalg.norm(res["sample"] - want) / np.linalg.norm(want))
         line["parity_rel_l2_first_rows"] = rel
         if not rel <= 1e-6:
             raise SystemExit("bench: GPU rows differ from the numpy guard (rel %.3e)" % rel)
 
-    if world == 1 and not args.no_extra and args.workload == "batch8192x4096":
-        ex = run_gpu(args, "batch1024x32768", rank, world, dist, torch, args.steps, args.warmup, args.sets)
+    if world == 1 and not args.no_extra and args.workload == "batch8192x4096" and not args.window:
+        # Everything in `extra` is informational.  Each figure: the same clock pre-warm as the headline, then the MEDIAN of
+        # EXTRA_REGIONS timed regions of K' steps (HIP events per region) -- not one sample of a 20-step region.
+        R = EXTRA_REGIONS
+        ex_steps = max(20, min(args.steps, 200))
+        ex = run_gpu(args, "batch1024x32768", rank, world, dist, torch, ex_steps, args.warmup, args.sets, repeats=R)
         exb = (2 * ex["hop"] + 4 * ex["n"]) * ex["frames"]
-        line["extra"] = {"fft_frames_per_sec_n1024": ex["frames"] / (ex["kernel_ms"] * 1e-3),
+        line["extra"] = {"timed_regions_per_figure": R,
+                         "fft_frames_per_sec_n1024": ex["frames"] / (ex["kernel_ms"] * 1e-3),
                          "msamples_per_sec_n1024": ex["frames"] / (ex["kernel_ms"] * 1e-3) * ex["hop"] / 1e6,
                          "roofline_frac_n1024": exb / (ex["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel_n1024": ex["kernel"], "avg_launch_ms_n1024": ex["kernel_ms"]}
@@ -701,27 +843,60 @@ def main():
         # double-buffered consumer of independent batches gets; informational, never `value` (host wall clock)
         line["extra"].update({"two_stream_frames_per_sec_n8192": res["two_stream"],
                               "two_stream_frames_per_sec_n1024": ex["two_stream"]})
-        # BASELINE.json's other single-GPU-measurable configurations, shorter runs (informational)
-        st_steps = max(10, min(args.steps, 300))
-        st = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2)
+        # the taper window north_star names, fused into pass 0 (fsea_plan_set_window): the headline batch and BASELINE config
+        # 5's 50 %-overlap STFT with a Hann taper, each beside its rectangular twin measured the same way in this run
+        h_steps = max(20, min(args.steps, 200))
+        r8 = run_gpu(args, "batch8192x4096", rank, world, dist, torch, h_steps, args.warmup, args.sets, repeats=R)
+        h8 = run_gpu(args, "batch8192x4096", rank, world, dist, torch, h_steps, args.warmup, args.sets, repeats=R, window="hann")
+        st_steps = max(20, min(args.steps, 100))
+        st = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2, repeats=R)
+        sh = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2, repeats=R, window="hann")
+        for tag, run_ in (("hann_n8192", h8), ("stft16384_hann", sh)):
+            want = numpy_rows(run_["host_head"], 4, run_["n"], run_["hop"], window="hann")
+            relw = float(np.linalg.norm(run_["sample"] - want) / np.linalg.norm(want))
+            if not relw <= 1e-6:
+                raise SystemExit("bench: windowed rows (%s) differ from the numpy guard (rel %.3e)" % (tag, relw))
         stb = (2 * st["hop"] + 4 * st["n"]) * st["frames"]
         line["extra"].update({"stft16384_hop8192_frames_per_sec": st["frames"] / (st["kernel_ms"] * 1e-3),
-                              "stft16384_roofline_frac": stb / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS})
-        br = run_broad(args, rank, world, dist, torch, 20, 3)
+                              "stft16384_roofline_frac": stb / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "stft16384_kernel": st["kernel"],
+                              "stft16384_hann_frames_per_sec": sh["frames"] / (sh["kernel_ms"] * 1e-3),
+                              "stft16384_hann_roofline_frac": stb / (sh["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "stft16384_hann_kernel": sh["kernel"],
+                              "stft16384_hann_over_rect": st["kernel_ms"] / sh["kernel_ms"],
+                              "hann_n8192_frames_per_sec": h8["frames"] / (h8["kernel_ms"] * 1e-3),
+                              "hann_n8192_roofline_frac": alg_bytes / (h8["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "hann_n8192_kernel": h8["kernel"],
+                              "hann_n8192_over_rect": r8["kernel_ms"] / h8["kernel_ms"]})
+        line["extra"].update(energy_per_frame(torch))
+        br = run_broad(args, rank, world, dist, torch, 20, 3, repeats=R)
         line["extra"].update({"broad_sweep_1gpu_frames_per_sec": br["value"], "broad_sweep_1gpu_ms": br["ms_per_step"],
-                              "broad_sweep_roofline_frac": br["roofline"]["frac"]})
+                              "broad_sweep_1gpu_kernel_ms": br["ms_per_step_kernel_events"],
+                              "broad_sweep_1gpu_host_issue_ms": br["host_issue_ms_per_step"],
+                              "broad_sweep_1gpu_ms_two_streams": br["ms_per_step_two_streams"],
+                              "broad_sweep_roofline_frac": br["roofline"]["frac"],
+                              "broad_sweep_roofline_frac_by_step_time": br["roofline_frac_by_step_time"],
+                              "broad_sweep_note": "ms = host wall clock per whole-sweep step (K = 20, median of the timed regions); "
+                                                  "kernel_ms = the tiled FFT launch by HIP events; the difference is the first "
+                                                  "submission + last synchronise of a 20-step region (a few tens of us) spread "
+                                                  "over its steps, plus Python's per-step issue time where that exceeds the kernel"})
         line["extra"].update(host_path_rate(n, frames))
         line["extra"].update(nrf_stream_rate())
         # what bounds the headline kernel from above on THIS box, same launch shape and buffer rotation: its I/O skeleton
-        # and a plain 1 : 2 read/write stream (tuning library, in a subprocess: scripts/skeleton_rates.py)
+        # and a plain 1 : 2 read/write stream (tuning library, in a subprocess: scripts/skeleton_rates.py).  The subprocess
+        # measures the product kernel the same way beside them: the RATIOS are what compares like with like.
         sk = skeleton_rates()
         if sk:
             line["roofline"].update({"io_skeleton_frac": sk["io_skeleton_frac"], "copy_frac": sk["copy_frac"],
                                      "io_skeleton_launch_ms": sk["io_skeleton_launch_ms"], "copy_launch_ms": sk["copy_launch_ms"],
                                      "product_frac_in_that_process": sk["product_frac"],
+                                     "kernel_over_io_skeleton": sk["product_frac"] / sk["io_skeleton_frac"],
+                                     "kernel_over_copy": sk["product_frac"] / sk["copy_frac"],
                                      "ceiling_note": "io_skeleton = this kernel's loads and row stores without LDS exchange and "
                                                      "butterflies (abl_io_nt); copy = a plain 16-bytes-in / 32-bytes-out nt "
-                                                     "stream; scripts/skeleton_rates.py in this run"})
+                                                     "stream; all three measured alike in one subprocess (scripts/skeleton_rates.py: "
+                                                     "0.25 s pre-warm, median of 5 rounds of 120 launches): compare the kernel with "
+                                                     "them through kernel_over_*, not through `frac`"})
 
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cores, quota_note = effective_cpus()
