@@ -345,6 +345,8 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
         got = img[:2, :n].cpu().numpy()
         check = int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())
         # the stitched image against the plain tile stack of this rank's shard (same kernel, untiled rows)
+        plan.exec_device(iq.data_ptr(), (hi - lo) * rows, px.data_ptr(), flip=True, stream=stream)
+        torch.cuda.synchronize()
         stack = px.view(hi - lo, rows, n)
         for k in (0, (hi - lo) // 2, hi - lo - 1):
             if not torch.equal(img[:, (lo + k) * n:(lo + k + 1) * n], stack[k]):
@@ -373,7 +375,7 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
         # the step by its own clock and by the FFT kernel's: the difference is what the host spends per step that is not
         # hidden behind the device (first submission and last synchronise of the K-step region, spread over K)
         "ms_per_step_kernel_events": kernel_ms, "host_issue_ms_per_step": host_issue_ms,
-        "roofline_frac_by_step_time": alg / (1e-3 * wall / steps) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
+        "roofline_frac_by_step_time": alg / (wall / steps) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
         "ms_per_step_two_streams": two_stream_ms, "timed_regions": max(1, repeats),
     }
     plan.close()
@@ -410,6 +412,8 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
         a, b = max(b0, s_lo), min(b1, s_hi)
         iq[2 * (a - s_lo): 2 * (b - s_lo)] = stream_block(torch, dev, blk, block_samples)[2 * (a - b0): 2 * (b - b0)]
     plan = fsea.Plan(n, hop=hop, mode=fsea.MODE_MAG_F32, device=dev.index)
+    if args.window:
+        plan.set_window(args.window)
     out = torch.empty((total_frames, n), dtype=torch.float32, device=dev) if rank == 0 else None
     # rank 0 transforms its own frames straight into the gathered array; the others into a send buffer
     rows = out[f_lo:f_hi] if rank == 0 else torch.empty((f_hi - f_lo, n), dtype=torch.float32, device=dev)
@@ -453,7 +457,7 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
     rel = None
     if rank == 0:                                               # rows 0, 1 and the last one against numpy
         head = stream_block(torch, dev, 0, block_samples)[: 2 * (hop + n)].cpu().numpy().view(np.uint8)
-        want = numpy_rows(head, 2, n, hop)
+        want = numpy_rows(head, 2, n, hop, window=args.window)
         got = out[:2].cpu().numpy()
         rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
         if not rel <= 1e-6:
@@ -464,8 +468,10 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * wall / steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "msamples_per_sec": total_frames * steps / wall * hop / 1e6,
-        "config": {"workload": "stft16384stream: one 20 Msps-style int8 stream, %d frames of 16384 points at hop 8192, "
-                               "f32 magnitude rows gathered to rank 0" % total_frames,
+        "config": {"workload": "stft16384stream: one 20 Msps-style int8 stream, %d frames of 16384 points at hop 8192, %s, "
+                               "f32 magnitude rows gathered to rank 0" %
+                               (total_frames, "%s taper fused into pass 0" % args.window if args.window else "rectangular frames"),
+                   "window": args.window or "rectangular (the reference)",
                    "regime": "resident: every rank's samples (frames + 8192-sample halo) are in HBM when the step starts",
                    "gather_chunks": n_chunks,
                    "parallelism": "frame ranges x%d with an N - hop halo read redundantly, rows gathered by grouped send/recv" % world},
