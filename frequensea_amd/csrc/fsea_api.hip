@@ -25,6 +25,7 @@
 using namespace fsea_detail;
 
 extern "C" int fsea_kernels_small(fsea::KernelEntry *out, int cap);
+extern "C" int fsea_kernels_alt(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_1024(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_2048(fsea::KernelEntry *out, int cap);
 extern "C" int fsea_kernels_4096(fsea::KernelEntry *out, int cap);
@@ -68,7 +69,7 @@ const std::vector<fsea::KernelEntry> &registry() {
     static std::vector<fsea::KernelEntry> all = [] {
         std::vector<fsea::KernelEntry> v;
         fsea::KernelEntry tmp[32];
-        int (*lists[])(fsea::KernelEntry *, int) = {fsea_kernels_small, fsea_kernels_1024, fsea_kernels_2048,
+        int (*lists[])(fsea::KernelEntry *, int) = {fsea_kernels_small, fsea_kernels_alt, fsea_kernels_1024, fsea_kernels_2048,
                                                     fsea_kernels_4096,  fsea_kernels_8192, fsea_kernels_16384,
 #ifdef FSEA_TUNE
                                                     fsea_kernels_tune_8192a, fsea_kernels_tune_8192b,
@@ -605,8 +606,22 @@ static int create_plan(fsea_plan **out, int fft_size, int hop, int mode, int dev
     return FSEA_OK;
 }
 
+// The configuration a plan of (fft_size, mode) takes where the modes of a size prefer different radix orders
+// (fsea_configs.h: FSEA_CFG_256_ROWS, FSEA_CFG_512_PX, FSEA_CFG_1024_RT); "" = the size's first configuration.
+static const char *preferred_variant(int fft_size, int mode) {
+    const bool f32_rows = mode == FSEA_MODE_MAG_F32 || mode == FSEA_MODE_MAG_NODC_F32 || mode == FSEA_MODE_DB_F32;
+    const bool pixels = mode == FSEA_MODE_DB10_U8 || mode == FSEA_MODE_DB5_U8_DCFIX;
+    if (fft_size == 256 && f32_rows) return "rows";
+    if (fft_size == 512 && pixels) return "px";
+    // 1024 points: the modes only the run-time-mode kernel serves (COMPLEX_F32, MAG_NODC_F32, DB_F32)
+    if (fft_size == 1024 && (mode == FSEA_MODE_COMPLEX_F32 || mode == FSEA_MODE_MAG_NODC_F32 || mode == FSEA_MODE_DB_F32)) return "rt";
+    return "";
+}
+
 int fsea_plan_create(fsea_plan **out, int fft_size, int hop, int mode, int device) {
-    return create_plan(out, fft_size, hop, mode, device, "");
+    const char *variant = std::getenv("FSEA_ONE_CONFIG_PER_SIZE") ? "" : preferred_variant(fft_size, mode);  // (A/B measurements)
+    if (variant[0] && !find_entry(fft_size, variant)) variant = "";
+    return create_plan(out, fft_size, hop, mode, device, variant);
 }
 
 // Recovery: waits for the device and zeroes every ticket-counter slot (a launch that was aborted

@@ -26,6 +26,21 @@
 #define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 6328478
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 6328456
 
+// Per-(size, mode) configurations: where the modes of one size prefer different radix orders, a plan takes the one its
+// mode prefers (fsea_api.hip: preferred_variant; registry variants "rows" / "px" / "rt", full kernel sets).  Measured in one
+// process against the size's first configuration (profiles/r03_layouts_other_sizes.txt, r03_1024_three_pass.txt,
+// r04_mode_rates.txt):
+//   256 points, f32 rows (MAG, MAG_NODC, DB_F32): 4 x 8 x 8 -- dwordx4 pass-0 loads, four adjacent bins per lane: +4 %
+//       (the 16 x 16 of FSEA_CFG_256 stays the pixel layout: c/fft-batch-broad.c's own size, -13 % as 4 x 8 x 8);
+//   512 points, u8 pixels (DB10, DB5): 16 x 32 -- one pixel per lane and store, dword loads: +11 % (f32 rows: -3 %);
+//   1024 points, the modes of the run-time-mode kernel (COMPLEX_F32, MAG_NODC_F32, DB_F32): the 32 x 32 layout of round 2 --
+//       one bin per lane = one 8-byte complex store per row, where the 8 x 16 x 8 of FSEA_CFG_1024 holds four bins per lane,
+//       two 16-byte stores each writing every other 16 bytes of the row: 0.297 against 0.208 ms per 2^27 samples; the f32
+//       rows of that kernel 0.164 against 0.153 ms (the compile-time MAG and pixel kernels prefer 8 x 16 x 8).
+#define FSEA_CFG_256_ROWS 256, 8, 32, 2, 3, 4, 8, 8, 1, true, true, 0, 6328478
+#define FSEA_CFG_512_PX 512, 16, 16, 2, 2, 16, 32, 1, 1, true, true, 0, 6328330
+#define FSEA_CFG_1024_RT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 6295562
+
 // Windowed kernels (FftKernel<..., WIN>; fsea_plan_set_window): the lane's P taper weights stay in registers for the
 // workgroup's lifetime at every size (WIN = 2).  Fetching them again for every frame (WIN = 1, the tuning library's "w1"
 // variants) frees 32 registers between pass 0 and the last pass and loses 2-5 % to the extra loads

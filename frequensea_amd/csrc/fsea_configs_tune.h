@@ -151,7 +151,7 @@
 #define FSEA_CFG_256_PK 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 2101248
 #define FSEA_CFG_256_PX0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 4096
 #define FSEA_CFG_1024_PX0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 4106
-#define FSEA_CFG_1024_R2 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 6295562   /* the round-2 layout (32 x 32) with round 3's pixel epilogue */
+#define FSEA_CFG_1024_R2 FSEA_CFG_1024_RT   /* the round-2 layout (32 x 32) with round 3's pixel epilogue */
 // 256 points with 64 points per lane (4 lanes per frame, 16 x 16 with four columns: dwordx2 loads, four adjacent bins per
 // lane in the last pass), one wave per workgroup, one wave per SIMD
 #define FSEA_CFG_256_P64 256, 4, 16, 1, 2, 16, 16, 1, 1, true, true, 0, 4096
@@ -176,8 +176,8 @@
 // Round 3, after 1024 gained from wider pass-0 loads and four bins per lane: the same question at the other sizes
 // (full u8 kernel sets with the product's options; names = the radix order)
 #define FSEA_CFG_512_888 512, 16, 16, 2, 3, 8, 8, 8, 1, true, true, 0, 6328478
-#define FSEA_CFG_512_1632 512, 16, 16, 2, 2, 16, 32, 1, 1, true, true, 0, 6328330
-#define FSEA_CFG_256_488 256, 8, 32, 2, 3, 4, 8, 8, 1, true, true, 0, 6328478
+#define FSEA_CFG_512_1632 FSEA_CFG_512_PX       /* product for the pixel modes since round 4 */
+#define FSEA_CFG_256_488 FSEA_CFG_256_ROWS     /* product for the f32-row modes since round 4 */
 #define FSEA_CFG_256_884 256, 8, 32, 2, 3, 8, 8, 4, 1, true, true, 0, 6328478
 #define FSEA_CFG_128_448 128, 4, 64, 2, 3, 4, 4, 8, 1, true, true, 0, 6328478
 #define FSEA_CFG_2048_81616 2048, 64, 4, 2, 3, 8, 16, 16, 1, true, true, 0, 6328478

@@ -162,7 +162,9 @@ class Plan:
         self.hop = fft_size if hop is None else hop
         self.mode = mode
         self.device = device
-        if not variant:
+        # variant None: the product plan (its mode's configuration of the size); "" (tuning library): the size's first
+        # configuration whatever the mode; a name: that tuning / per-mode configuration
+        if variant is None or (variant == "" and not hasattr(self._L, "fsea_plan_create_variant")):
             _check(self._L.fsea_plan_create(ctypes.byref(self._p), fft_size, self.hop, mode, device))
         elif not hasattr(self._L, "fsea_plan_create_variant"):
             raise FseaError("kernel variants live in libfsea_hip_tune.so: call fsea.use_tune_library() first")

@@ -49,3 +49,15 @@ def synth_iq(seed, n_bytes, tone_bin_frac=0.125, sigma=20.0, amp=40.0):
     iq[0::2] = i
     iq[1::2] = q
     return np.clip(np.rint(iq), -128, 127).astype(np.int8).view(np.uint8)
+
+
+def kernel_stem(n, mode):
+    """Symbol stem of the kernels a plan of (fft_size, mode) launches: where the modes of a size prefer different radix
+    orders the plan takes its mode's configuration (frequensea_amd/csrc/fsea_configs.h, fsea_api.hip: preferred_variant)."""
+    if n == 256 and mode in (0, 4, 5):
+        return "fsea_fft256rows"
+    if n == 512 and mode in (1, 2):
+        return "fsea_fft512px"
+    if n == 1024 and mode in (3, 4, 5):
+        return "fsea_fft1024rt"
+    return "fsea_fft%d" % n

@@ -97,6 +97,10 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     int mt = (specialised && has_fixed && in_kind == fsea::IN_U8 && flip) ? mode : -1;
     if (!g_window.empty() && mt != fsea::MODE_MAG) mt = -1;  // the windowed kernels: compile-time MAG, or run-time mode
     const std::string v = variant ? variant : "";
+    // the per-(size, mode) product configurations (fsea_configs.h)
+    if (n == 256 && v == "rows") return dispatch<fsea::FftCfg<FSEA_CFG_256_ROWS>>(in_kind, mt, a, grid);
+    if (n == 512 && v == "px") return dispatch<fsea::FftCfg<FSEA_CFG_512_PX>>(in_kind, mt, a, grid);
+    if (n == 1024 && v == "rt") return dispatch<fsea::FftCfg<FSEA_CFG_1024_RT>>(in_kind, mt, a, grid);
     if (!v.empty()) {
         int rc = emu_variants_a(n, v, in_kind, mt, a, grid);
         if (rc == -2) rc = emu_variants_b(n, v, in_kind, mt, a, grid);

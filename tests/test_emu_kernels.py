@@ -346,3 +346,27 @@ def test_window_tables_decide_the_form():
     assert not np.array_equal(a, b)
     parity.check_mode_windowed(a, iq, n, nf, n, True, 3, w)
     parity.check_mode_windowed(b, iq, n, nf, n, True, 3, w)
+
+
+# ---- per-(size, mode) product configurations (fsea_configs.h: FSEA_CFG_256_ROWS, FSEA_CFG_512_PX, FSEA_CFG_1024_RT) ----
+
+@pytest.mark.parametrize("n,variant", [(256, "rows"), (512, "px"), (1024, "rt")])
+def test_per_mode_product_configurations(n, variant):
+    """Full kernel sets: every mode, both byte conventions, f32 input, the frequency shift, a window, tiles."""
+    nf = 37
+    iq = synth_iq(900 + n, 2 * nf * n)
+    for mode in range(6):
+        for spec in (True, False):
+            got = emu_rows(iq, n, nf, mode=mode, specialised=spec, variant=variant)
+            parity.check_mode(got, iq, n, nf, n, True, mode)
+    off = iq ^ np.uint8(0x80)
+    parity.check_mode(emu_rows(off, n, nf, flip=False, mode=3, variant=variant), off, n, nf, n, False, 3)
+    got = emu_rows(iq, n, nf, mode=0, variant=variant, shift=(0.013, 0.2))
+    parity.check_mode_shifted(got, iq, n, nf, n, True, 0, 0.013, 0.2)
+    w = _taper("hann", n)
+    for mode in (0, 2, 3):
+        got = emu_rows(iq, n, nf, mode=mode, variant=variant, window=w)
+        parity.check_mode_windowed(got, iq, n, nf, n, True, mode, w)
+    hop = n // 2
+    got = emu_rows(iq, n, 2 * nf - 1, hop=hop, variant=variant)
+    parity.check_mode(got, iq, n, 2 * nf - 1, hop, True, 0)

@@ -11,7 +11,7 @@ import pytest
 from frequensea_amd import fsea, nrf
 from oracle import oracle as O
 from tests import parity
-from tests.conftest import ALL_CAPTURE_KEYS, GOLDEN_KEYS, GOLDEN_SIZES, ROOT, synth_iq
+from tests.conftest import ALL_CAPTURE_KEYS, GOLDEN_KEYS, GOLDEN_SIZES, ROOT, kernel_stem, synth_iq
 
 pytestmark = pytest.mark.gpu
 
@@ -217,6 +217,39 @@ def test_survey_known_answers_on_gpu(golden):
     assert abs(float(row.astype(np.float64).sum()) - 1567.312172) < 1e-2
     row = fsea.Plan(8192).exec_host(raw, 1)[0]
     assert row.argmax() == 3358 and abs(float(row.max()) - 162.437851) < 5e-4
+
+
+@pytest.mark.parametrize("n,mode", [(256, 0), (256, 4), (256, 5), (512, 1), (512, 2), (1024, 3), (1024, 4), (1024, 5)])
+def test_per_mode_configurations(n, mode, monkeypatch):
+    """Where the modes of one size prefer different radix orders a plan takes its mode's configuration (256 points: f32
+    rows; 512: u8 pixels; 1024: the run-time-mode kernel's modes -- full kernel sets): against the oracle through every entry point, and
+    against the size's first configuration (FSEA_ONE_CONFIG_PER_SIZE=1 at plan creation)."""
+    nf = 301
+    iq = synth_iq(60 + n + mode, 2 * nf * n)
+    plan = fsea.Plan(n, mode=mode)
+    suffix = {0: "_u8_mag", 1: "_u8_db10", 2: "_u8_db5"}.get(mode, "_u8")
+    assert plan.kernel_name == kernel_stem(n, mode) + suffix and kernel_stem(n, mode) != "fsea_fft%d" % n
+    got = plan.exec_host(iq, nf)
+    parity.check_mode(got, iq, n, nf, n, True, mode)
+    off = iq ^ np.uint8(0x80)
+    got_off = plan.exec_host(off, nf, flip=False)                        # the run-time-mode kernel of the same configuration
+    if mode in (1, 2):
+        assert np.array_equal(got, got_off)
+    parity.check_mode(got_off, off, n, nf, n, False, mode)
+    parity.check_mode_shifted(plan.exec_shifted_host(iq, nf, 0.0173, 0.25), iq, n, nf, n, True, mode, 0.0173, 0.25)
+    x = (off.astype(np.float64) / 256.0)
+    got64 = plan.exec_host_f64(x, nf)                                    # f64 input = u8 / 256 (src/nrf.c:607-609)
+    parity.check_mode(got64, off, n, nf, n, False, mode)
+    plan.close()
+    monkeypatch.setenv("FSEA_ONE_CONFIG_PER_SIZE", "1")
+    first = fsea.Plan(n, mode=mode)
+    assert first.kernel_name == "fsea_fft%d%s" % (n, suffix)
+    base = first.exec_host(iq, nf)
+    first.close()
+    if mode in (1, 2):
+        parity.check_u8(got, base)
+    elif mode != 5:                                                       # (dB of numerically empty bins: oracle check above)
+        assert np.linalg.norm(got.astype(np.complex128) - base) <= 1e-6 * np.linalg.norm(base)
 
 
 @pytest.mark.parametrize("n", [32, 256, 1024, 4096, 8192, 16384])

@@ -10,7 +10,7 @@ import pytest
 from frequensea_amd import fsea
 from oracle import oracle as O
 from tests import parity
-from tests.conftest import GOLDEN_KEYS, ROOT, synth_iq
+from tests.conftest import GOLDEN_KEYS, ROOT, kernel_stem, synth_iq
 from tests.test_gpu_parity import SIZES, DeviceBuffer, units_policy  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +36,7 @@ def test_windowed_mag_rows_all_sizes(n, wname):
     plan = fsea.Plan(n)
     plan.set_window(w)
     assert plan.window_form == (2 if wname == "random" else 1)
-    assert plan.kernel_name == "fsea_fft%d_u8_mag_win" % n
+    assert plan.kernel_name == kernel_stem(n, 0) + "_u8_mag_win"
     got = plan.exec_host(iq, nf)
     parity.check_mode_windowed(got, iq, n, nf, n, True, 0, w)
     assert np.array_equal(got[:, n // 2], got[:, n // 2 - 1])
@@ -52,7 +52,7 @@ def test_windowed_other_modes_and_byte_conventions(n, mode, wname):
     w = _window(wname, n, seed=mode)
     plan = fsea.Plan(n, mode=mode)
     plan.set_window(w)
-    assert plan.kernel_name == "fsea_fft%d_u8_win" % n
+    assert plan.kernel_name == kernel_stem(n, mode) + "_u8_win"
     for flip in (True, False):
         got = plan.exec_host(iq, nf, flip=flip)
         parity.check_mode_windowed(got, iq, n, nf, n, flip, mode, w)

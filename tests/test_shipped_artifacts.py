@@ -15,6 +15,7 @@ LIB = os.path.join(ROOT, "frequensea_amd", "libfsea_hip.so")
 SIZES = (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384)
 KINDS = ("u8_mag", "u8_db5", "u8_db10", "u8", "u8_rot", "f32")
 WIN_KINDS = ("u8_mag_win", "u8_win")
+ALT_CONFIGS = ("256rows", "512px", "1024rt")
 
 
 def _kernels(path):
@@ -65,7 +66,8 @@ def test_every_size_has_its_six_entry_points_and_nothing_experimental(kernels):
     fft = sorted(k for k in kernels if k.startswith("fsea_fft"))
     # + the half-overlap MAG kernels of the two sizes with one frame per workgroup (hop == N/2: every sample loaded once)
     # + the windowed kernels (fsea_plan_set_window): MAG, run-time mode, and the half-overlap MAG kernels again
-    assert fft == sorted(["fsea_fft%d_%s" % (n, kind) for n in SIZES for kind in KINDS + WIN_KINDS] +
+    # + the per-(size, mode) configurations: 256 points for f32 rows, 512 for u8 pixels, 1024 for COMPLEX_F32 rows (full sets)
+    assert fft == sorted(["fsea_fft%s_%s" % (n, kind) for n in SIZES + ALT_CONFIGS for kind in KINDS + WIN_KINDS] +
                          ["fsea_fft%d_u8_mag_half%s" % (n, w) for n in (8192, 16384) for w in ("", "_win")])
     assert not [k for k in kernels if "abl" in k]
 
@@ -74,9 +76,9 @@ def test_hot_kernels_do_not_spill(kernels):
     for name in ["fsea_fft%d_u8_mag_half%s" % (n, w) for n in (8192, 16384) for w in ("", "_win")]:
         k = kernels[name]
         assert k[".vgpr_count"] <= 256 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, name
-    for n in SIZES:
+    for n in SIZES + ALT_CONFIGS:
         for kind in KINDS + WIN_KINDS:
-            k = kernels["fsea_fft%d_%s" % (n, kind)]
+            k = kernels["fsea_fft%s_%s" % (n, kind)]
             assert k[".vgpr_count"] <= 256 and k[".wavefront_size"] == 64
             if (n, kind) == (1024, "u8_win"):
                 # the run-time-mode windowed kernel at 1024 points (four bins per lane, 32 weights in flight): 4 registers
