@@ -6,65 +6,47 @@
 
 // round-1 configurations of the sizes whose product configuration changed in round 2
 // (OPT 256: +-i butterflies as packed FMAs; no deferred twiddles)
-#define FSEA_CFG_8192_R1 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 286
-#define FSEA_CFG_16384_R1 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 264
-#define FSEA_CFG_1024_R1 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 266
 // packed-add +-i butterflies without the deferred twiddles
-#define FSEA_CFG_8192_ND 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 30
-#define FSEA_CFG_16384_ND 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 8
+#define FSEA_CFG_8192_ND 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_16384_ND 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::TW_FUSE
 // deferred twiddles on the sizes that did not gain from them
-#define FSEA_CFG_4096_DF 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 138
-#define FSEA_CFG_2048_DF 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 142
+#define FSEA_CFG_4096_DF 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, fo::DEFER | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_2048_DF 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::DEFER | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // OPT 512 (late ticket wait) and OPT 1024 (static priority for one of the two co-resident workgroups)
-#define FSEA_CFG_8192_TK 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 670
-#define FSEA_CFG_8192_PR 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 1182
 // cache policy of the input loads / output stores (OPT 4096 nt stores, 8192 sc1, 16384 sc0, 32768 nt loads):
 // "cp0" = default policy for both (the round-2 kernel before the policy was chosen), then the alternatives
-#define FSEA_CFG_8192_CP0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 158
-#define FSEA_CFG_8192_STNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 4254
-#define FSEA_CFG_8192_STSC1 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 8350
-#define FSEA_CFG_8192_STSC01 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 24734
-#define FSEA_CFG_8192_STSC1NT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 12446
-#define FSEA_CFG_8192_LDNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 32926
-#define FSEA_CFG_16384_CP0 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 136
-#define FSEA_CFG_16384_STNT 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 4232
-#define FSEA_CFG_4096_CP0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 158
-#define FSEA_CFG_4096_STNT 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 4254
-#define FSEA_CFG_2048_CP0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 14
-#define FSEA_CFG_2048_STNT 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 4110
-#define FSEA_CFG_1024_CP0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 10
-#define FSEA_CFG_1024_LDSTNT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 36874
+#define FSEA_CFG_8192_CP0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_STNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_LDNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_16384_CP0 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::DEFER | fo::TW_FUSE
+#define FSEA_CFG_16384_STNT 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::ST_NT | fo::DEFER | fo::TW_FUSE
+#define FSEA_CFG_4096_CP0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_STNT 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_2048_CP0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_2048_STNT 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::ST_NT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_1024_CP0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_1024_LDSTNT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::TW_FUSE | fo::BATCH_READS
 #define FSEA_CFG_256_CP0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 0
-#define FSEA_CFG_256_LDSTNT 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 36864
+#define FSEA_CFG_256_LDSTNT 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::LD_NT | fo::ST_NT
 // V2 schedule (OPT 64): first exchange inside each wavefront, two barriers per frame; with its
 // measurement-only ablations (8: static units + early prefetch, 16: V1 load mapping, wrong results,
 // 32: no first exchange, wrong results)
-#define FSEA_CFG_8192_V2 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 74
-#define FSEA_CFG_8192_V2S 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 8, 74
-#define FSEA_CFG_8192_V2L 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 16, 74
-#define FSEA_CFG_8192_V2SL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 24, 74
-#define FSEA_CFG_8192_V2NA 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 32, 74
+#define FSEA_CFG_8192_V2 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::V2 | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_8192_V2S 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::V2_STATIC, fo::V2 | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_8192_V2L 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::V2_V1_LOADS, fo::V2 | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_8192_V2SL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::V2_V1_LOADS | fsea::abl::V2_STATIC, fo::V2 | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_8192_V2NA 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::V2_NO_EXCHANGE_A, fo::V2 | fo::TW_FUSE | fo::BATCH_READS
 // other pass orders with round 2's options: 16 x 32 x 16 (8-byte row stores), 8 x 32 x 32 (8-byte loads)
-#define FSEA_CFG_8192_B2 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 37022
-#define FSEA_CFG_8192_D2 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 37022
+#define FSEA_CFG_8192_B2 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_D2 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // 32 x 32 x 8: four adjacent bins per lane in the last pass (16-byte row stores), 2-byte pass-0 loads; with and without nt loads
 // issue priority between the two workgroups of a CU: alternating per frame (65536), catching up with the pool's average (131072)
-#define FSEA_CFG_8192_PALT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 102558
 // the younger workgroup of every CU (block >= grid / 2) at a constant higher priority (the older one wins the arbitration
 // otherwise: 39 vs 53 us for the same 8 frames), levels 1, 2, 3
-#define FSEA_CFG_8192_PY1 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 38046
 // the last pass's register twiddles each gathered directly from the two factor tables (the form up to mid round 2)
-#define FSEA_CFG_8192_TWE 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 561310
-#define FSEA_CFG_4096_TWE 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 561342
-#define FSEA_CFG_1024_TWE 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 528394
-#define FSEA_CFG_8192_PPAIR 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 299166
-#define FSEA_CFG_8192_PCATCH 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 168094
-#define FSEA_CFG_4096_STATIC 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 39102
-#define FSEA_CFG_16384_STATIC 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 39048
 // static unit interleave (unit = blockIdx + k * grid) instead of the ticket pools
-#define FSEA_CFG_8192_STATIC 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 39070
-#define FSEA_CFG_8192_W 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, 37022
-#define FSEA_CFG_8192_W2 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, 4254
+#define FSEA_CFG_8192_W 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_W2 8192, 256, 1, 2, 3, 32, 32, 8, 1, true, true, 0, fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // other pass orders / twiddle sources
 #define FSEA_CFG_8192_A 8192, 256, 1, 2, 3, 32, 16, 16, 1, true, true
 #define FSEA_CFG_8192_B 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true
@@ -78,131 +60,112 @@
 #define FSEA_CFG_4096_C 4096, 128, 2, 2, 3, 16, 8, 32, 1, true, true
 #define FSEA_CFG_4096_D 4096, 128, 2, 2, 3, 8, 16, 32, 1, true, true
 // small sizes with 16 points per lane (2-byte pass-0 loads), as in round 1 and round 2a
-#define FSEA_CFG_256_P16 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true, 0, 4096
-#define FSEA_CFG_128_P16 128, 8, 32, 2, 2, 16, 8, 1, 1, true, true, 0, 4096
+#define FSEA_CFG_256_P16 256, 16, 16, 2, 2, 16, 16, 1, 1, true, true, 0, fo::ST_NT
+#define FSEA_CFG_128_P16 128, 8, 32, 2, 2, 16, 8, 1, 1, true, true, 0, fo::ST_NT
 // 4096 as in rounds 1 and 2a: 256 lanes x 16 points, four workgroups per CU (with and without the streaming policy);
 // "B" is the 128-lane layout without round 2's options, "B3" the product layout without deferred twiddles
-#define FSEA_CFG_4096_R1 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 266
-#define FSEA_CFG_4096_T256 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 36874
-#define FSEA_CFG_4096_F1 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, 37022
-#define FSEA_CFG_4096_B3 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 36894
+#define FSEA_CFG_4096_T256 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_4096_F1 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_B3 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // lane rotation against LDS read conflicts (OPT 16 = middle pass, 32 = last pass) switched OFF where the product has it:
 // 4096 without the last-pass rotation, 2048 without the middle-pass rotation (scripts/lds_conflicts.py predicts 2 cycles
 // per ds_read_b128 group; measured SQ_LDS_BANK_CONFLICT 4.3 M / 8.5 M cycles per launch against 0.1 M / 4.3 M with it)
-#define FSEA_CFG_4096_LR 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 37022   /* "nr": without the last-pass rotation */
-#define FSEA_CFG_2048_LR 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 36878      /* "nr": without the middle-pass rotation */
+#define FSEA_CFG_4096_LR 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* "nr": without the last-pass rotation */
+#define FSEA_CFG_2048_LR 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS      /* "nr": without the middle-pass rotation */
 #define FSEA_CFG_16384_B 16384, 512, 1, 2, 3, 32, 32, 16, 1, true, true
 #define FSEA_CFG_2048_B 2048, 64, 4, 2, 3, 8, 8, 32, 1, true, true
 #define FSEA_CFG_2048_C 2048, 64, 4, 2, 3, 4, 16, 32, 1, true, true
 // measurement-only ablations of the 8192-point kernel (results are wrong by design):
 // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies, 64 = no per-frame loads,
 // 128 = no magnitude arithmetic
-#define FSEA_CFG_8192_NOST 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 1, 30
-#define FSEA_CFG_8192_NOLDS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 2, 30
-#define FSEA_CFG_8192_NOFLOP 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4, 30
-#define FSEA_CFG_8192_IO 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6, 30
-#define FSEA_CFG_8192_VALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 3, 30
-#define FSEA_CFG_8192_IONT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 6, 36894
-#define FSEA_CFG_8192_NOLDSNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 2, 36894
-#define FSEA_CFG_8192_NOFLOPNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 4, 36894
-#define FSEA_CFG_8192_NOLOAD 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 64, 30
+#define FSEA_CFG_8192_NOST 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_STORES, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_NOLDS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_LDS, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_NOFLOP 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_FLOPS, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_IO 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_FLOPS | fsea::abl::NO_LDS, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_VALU 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_LDS | fsea::abl::NO_STORES, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_IONT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_FLOPS | fsea::abl::NO_LDS, fo::LD_NT | fo::ST_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_NOLDSNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_LDS, fo::LD_NT | fo::ST_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_NOFLOPNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_FLOPS, fo::LD_NT | fo::ST_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_NOLOAD 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_LOADS, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // 256 = the row stored 16 bytes per lane (bins misplaced), 512 = the frame loaded 16 bytes per lane (samples
 // misplaced): what layouts with 4 adjacent bins / 8 adjacent samples per lane would issue, without their other costs
-#define FSEA_CFG_8192_IONT_WS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 262, 36894
-#define FSEA_CFG_8192_IONT_WL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 518, 36894
-#define FSEA_CFG_8192_IONT_WLS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 774, 36894
-#define FSEA_CFG_8192_WS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 256, 37022
-#define FSEA_CFG_8192_WL 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 512, 37022
-#define FSEA_CFG_8192_WLS 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 768, 37022
 // the small sizes without nt stores, as full kernel sets: the pixel kernels' 16- and 32-byte row pieces are merged in L2
 // only when the stores are allowed to stay there
 #define FSEA_CFG_128_ST0 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, 0
 #define FSEA_CFG_256_ST0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 0
 #define FSEA_CFG_512_ST0 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, 0
-#define FSEA_CFG_1024_ST0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 10
+#define FSEA_CFG_1024_ST0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, fo::TW_FUSE | fo::BATCH_READS
 // pixel-mode ablations (full kernel sets, so that the compile-time DB5 / DB10 kernels exist): 128 = no logarithm,
 // 1 = no pixel stores, 256 = four pixels per dword store (misplaced), 6 = loads + epilogue only
-#define FSEA_CFG_4096_PXNOLOG 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 128, 37022
-#define FSEA_CFG_4096_PXNOST 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 1, 37022
-#define FSEA_CFG_4096_PXWIDE 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 256, 37022
-#define FSEA_CFG_4096_PXIO 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 6, 36894
-#define FSEA_CFG_4096_PXIOWIDE 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 262, 36894
-#define FSEA_CFG_8192_PXNOLOG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 128, 37022
-#define FSEA_CFG_8192_PXWIDE 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 256, 37022
-#define FSEA_CFG_8192_NOMAG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 128, 30
+#define FSEA_CFG_4096_PXNOLOG 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, fsea::abl::NO_EPILOGUE_MATH, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_PXNOST 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, fsea::abl::NO_STORES, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_PXIO 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, fsea::abl::NO_FLOPS | fsea::abl::NO_LDS, fo::LD_NT | fo::ST_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_PXNOLOG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_EPILOGUE_MATH, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_NOMAG 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::NO_EPILOGUE_MATH, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // schedule options of the defaults switched off (FftCfg::OPT), for A/B timing in one process
 #define FSEA_CFG_8192_X0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 0
-#define FSEA_CFG_8192_X7 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 7
 #define FSEA_CFG_4096_X0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 0
 #define FSEA_CFG_2048_X0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 0
 #define FSEA_CFG_1024_X0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 0
 // 4096 points as ONE wavefront per frame, 64 lanes x 64 points, no s_barrier (round 3):
 // "w64": 64 x 64, one exchange (FftKernel::run_w64; OPT 1048576), last-pass twiddles deferred and register-resident;
 // "s2": 16 x 16 x 16 in the V1 schedule, two exchanges, dwordx2 loads and four adjacent bins per lane in the last pass
-#define FSEA_CFG_4096_W64 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, 1085442
-#define FSEA_CFG_4096_S2 4096, 64, 1, 1, 3, 16, 16, 16, 1, true, true, 0, 37022
-#define FSEA_CFG_4096_W64B 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, 5279746   /* + biased rounding instead of v_trunc */
+#define FSEA_CFG_4096_W64 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, fo::W64 | fo::LD_NT | fo::ST_NT | fo::BATCH_READS
+#define FSEA_CFG_4096_S2 4096, 64, 1, 1, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_W64B 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, fo::PX_BIAS | fo::W64 | fo::LD_NT | fo::ST_NT | fo::BATCH_READS   /* + biased rounding instead of v_trunc */
 // pixel epilogue with v_cvt_pk_u8_f32 (OPT 2097152: v_trunc + convert-and-pack; + 4194304: biased rounding, no v_trunc)
 // "pk": with the v_trunc (exact truncation); "px0": the round-2 form (cast, clamp, shift/or); the product has both bits
-#define FSEA_CFG_4096_PK 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 2134206
-#define FSEA_CFG_4096_PX0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 37054
-#define FSEA_CFG_8192_PK 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 2134174
-#define FSEA_CFG_8192_PX0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 37022
-#define FSEA_CFG_256_PK 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 2101248
-#define FSEA_CFG_256_PX0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 4096
-#define FSEA_CFG_1024_PX0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 4106
+#define FSEA_CFG_4096_PK 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::PX_PACK | fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_PX0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_PK 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::PX_PACK | fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_PX0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_256_PK 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::PX_PACK | fo::ST_NT
+#define FSEA_CFG_256_PX0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::ST_NT
+#define FSEA_CFG_1024_PX0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, fo::ST_NT | fo::TW_FUSE | fo::BATCH_READS
 #define FSEA_CFG_1024_R2 FSEA_CFG_1024_RT   /* the round-2 layout (32 x 32) with round 3's pixel epilogue */
 // 256 points with 64 points per lane (4 lanes per frame, 16 x 16 with four columns: dwordx2 loads, four adjacent bins per
 // lane in the last pass), one wave per workgroup, one wave per SIMD
-#define FSEA_CFG_256_P64 256, 4, 16, 1, 2, 16, 16, 1, 1, true, true, 0, 4096
+#define FSEA_CFG_256_P64 256, 4, 16, 1, 2, 16, 16, 1, 1, true, true, 0, fo::ST_NT
 // pixel kernels at higher occupancy / finer workgroups (round 3; full u8 kernel sets with the product's pixel epilogue):
 // "t256px": 256 lanes x 16 points, four workgroups per CU = 4 waves per SIMD (round 1's layout: 2-byte loads, 1-byte stores);
 // "f1px": the product layout with one frame per workgroup (two waves, four workgroups per CU)
-#define FSEA_CFG_4096_T256PX 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, 6328330
-#define FSEA_CFG_4096_F1PX 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, 6328478
+#define FSEA_CFG_4096_T256PX 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_4096_F1PX 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // 32 and 64 points with two adjacent samples per lane in pass 0 (dword loads instead of 2-byte loads): 4 x 8 and 8 x 8
-#define FSEA_CFG_32_C2 32, 4, 64, 2, 2, 4, 8, 1, 1, true, true, 0, 6295552
-#define FSEA_CFG_64_C2 64, 4, 64, 2, 2, 8, 8, 1, 1, true, true, 0, 6295552
-#define FSEA_CFG_64_T2 64, 2, 128, 2, 2, 8, 8, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_32_C2 32, 4, 64, 2, 2, 4, 8, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+#define FSEA_CFG_64_C2 64, 4, 64, 2, 2, 8, 8, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+#define FSEA_CFG_64_T2 64, 2, 128, 2, 2, 8, 8, 1, 1, true, true, 0, fo::STREAMING_PIXELS
 // 1024 points in three passes with dword / dwordx2 pass-0 loads (the product's 32 x 32 loads 2 bytes per lane and row):
 // "e" = 16 x 8 x 8, "f" = 8 x 16 x 8, "g" = 16 x 16 x 4; 32 lanes x 32 points, no barrier (single-wave frames), two exchanges
-#define FSEA_CFG_1024_E 1024, 32, 8, 2, 3, 16, 8, 8, 1, true, true, 0, 6328350
-#define FSEA_CFG_1024_F 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328350
-#define FSEA_CFG_1024_G 1024, 32, 8, 2, 3, 16, 16, 4, 1, true, true, 0, 6328350
-#define FSEA_CFG_1024_H 1024, 32, 8, 2, 3, 8, 8, 16, 1, true, true, 0, 6328350
-#define FSEA_CFG_1024_FD 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328478   /* f + deferred middle-pass twiddles */
-#define FSEA_CFG_1024_F0 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6328334   /* f without the middle-pass lane rotation (OPT 16) */
-#define FSEA_CFG_1024_FL 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 6295582   /* f without nt loads */
+#define FSEA_CFG_1024_E 1024, 32, 8, 2, 3, 16, 8, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_1024_F 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_1024_G 1024, 32, 8, 2, 3, 16, 16, 4, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_1024_H 1024, 32, 8, 2, 3, 8, 8, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_1024_FD 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* f + deferred middle-pass twiddles */
+#define FSEA_CFG_1024_F0 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* f without the middle-pass lane rotation (OPT 16) */
+#define FSEA_CFG_1024_FL 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* f without nt loads */
 // Round 3, after 1024 gained from wider pass-0 loads and four bins per lane: the same question at the other sizes
 // (full u8 kernel sets with the product's options; names = the radix order)
-#define FSEA_CFG_512_888 512, 16, 16, 2, 3, 8, 8, 8, 1, true, true, 0, 6328478
+#define FSEA_CFG_512_888 512, 16, 16, 2, 3, 8, 8, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_512_1632 FSEA_CFG_512_PX       /* product for the pixel modes since round 4 */
 #define FSEA_CFG_256_488 FSEA_CFG_256_ROWS     /* product for the f32-row modes since round 4 */
-#define FSEA_CFG_256_884 256, 8, 32, 2, 3, 8, 8, 4, 1, true, true, 0, 6328478
-#define FSEA_CFG_128_448 128, 4, 64, 2, 3, 4, 4, 8, 1, true, true, 0, 6328478
-#define FSEA_CFG_2048_81616 2048, 64, 4, 2, 3, 8, 16, 16, 1, true, true, 0, 6328478
-#define FSEA_CFG_4096_16328 4096, 128, 2, 2, 3, 16, 32, 8, 1, true, true, 0, 6328510
-#define FSEA_CFG_4096_83216 4096, 128, 2, 2, 3, 8, 32, 16, 1, true, true, 0, 6328510
-#define FSEA_CFG_8192_163216 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, 6328478
-#define FSEA_CFG_8192_83232 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, 6328478
+#define FSEA_CFG_256_884 256, 8, 32, 2, 3, 8, 8, 4, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_128_448 128, 4, 64, 2, 3, 4, 4, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_2048_81616 2048, 64, 4, 2, 3, 8, 16, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_16328 4096, 128, 2, 2, 3, 16, 32, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096_83216 4096, 128, 2, 2, 3, 8, 32, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_163216 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_83232 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // OPT 8388608: the last butterfly level of the last pass in power form (dft_regs_tw_pw) in the MAG / DB10 / DB5 kernels;
 // "pw" = the product configuration + that bit; the small sizes do not fuse the last pass's twiddles (OPT 8) in the
 // product, which the power form builds on: "f8" = product + OPT 8, "pw" = product + OPT 8 + power form
-#define FSEA_CFG_8192_PW 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, 14717086
-#define FSEA_CFG_16384_PW 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, 14717064
-#define FSEA_CFG_4096_PW 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, 14717118
-#define FSEA_CFG_2048_PW 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 14716958
-#define FSEA_CFG_1024_PW 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, 14717086
-#define FSEA_CFG_512_F8 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, 6295560
-#define FSEA_CFG_512_PW 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, 14684168
-#define FSEA_CFG_256_F8 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 6295560
-#define FSEA_CFG_256_PW 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 14684168
-#define FSEA_CFG_128_PW 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, 14684168
+#define FSEA_CFG_512_F8 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::TW_FUSE
+#define FSEA_CFG_256_F8 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::TW_FUSE
 // 32 / 64 points with two lanes per frame (16 / 32 points per lane): radix orders by pass-0 load width and bins per lane
 //   32: "t2a" 4 x 8 (8-byte loads, 2 bins per lane), "t2b" 8 x 4 (dword loads, 4 bins), "t2c" 2 x 16 (16-byte loads, 1 bin)
 //   64: "t2c" 16 x 4 (dword loads, 8 bins per lane), "t2d" 4 x 16 (16-byte loads, 2 bins)
-#define FSEA_CFG_32_T2A 32, 2, 128, 2, 2, 4, 8, 1, 1, true, true, 0, 6295552
-#define FSEA_CFG_32_T2B 32, 2, 128, 2, 2, 8, 4, 1, 1, true, true, 0, 6295552
-#define FSEA_CFG_32_T2C 32, 2, 128, 2, 2, 2, 16, 1, 1, true, true, 0, 6295552
-#define FSEA_CFG_64_T2C 64, 2, 128, 2, 2, 16, 4, 1, 1, true, true, 0, 6295552
-#define FSEA_CFG_64_T2D 64, 2, 128, 2, 2, 4, 16, 1, 1, true, true, 0, 6295552
+#define FSEA_CFG_32_T2A 32, 2, 128, 2, 2, 4, 8, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+#define FSEA_CFG_32_T2B 32, 2, 128, 2, 2, 8, 4, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+#define FSEA_CFG_32_T2C 32, 2, 128, 2, 2, 2, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+#define FSEA_CFG_64_T2C 64, 2, 128, 2, 2, 16, 4, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+#define FSEA_CFG_64_T2D 64, 2, 128, 2, 2, 4, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS

@@ -19,6 +19,10 @@
 #include <stdint.h>
 
 #include <fsea_pk_asm.h>  // cf (packed complex), pk_cmul
+#include "fsea_opt.h"     // opt::..., abl::...
+#ifdef FSEA_TUNE
+#include <fsea_pk_asm_tune.h>  // cross-lane primitives of the tuning library's W64 schedule
+#endif
 
 namespace fsea {
 
@@ -84,22 +88,16 @@ __device__ __forceinline__ cf cf_fma(cf a, cf b, cf c) { return __builtin_elemen
 // and a branch around an asm statement is only removed when its condition is a constant expression.
 //   plus  = a + wr * b + (-wi, wi) * swap(b)      2 pk_fma (1 when wr == 0)
 //   minus = 2 a - plus                            1 pk_fma
-template <int L, int K, bool MI = true>
+template <int L, int K>
 __device__ __forceinline__ void bfly_const(cf &a, cf &b) {
     if constexpr (K == 0) {
         const cf t = b;
         b = a - t;
         a = a + t;
-    } else if constexpr (4 * K == L) {  // w = -i : w b = (b.y, -b.x)
-        if constexpr (MI) {
-            const cf t = b;
-            b = pk_add_pi(a, t);
-            a = pk_add_mi(a, t);
-        } else {  // the round-1 form: two packed FMAs with (+-1, -+1)
-            const cf sb = cf_swap(b);
-            b = cf_fma(sb, cf{-1.0f, 1.0f}, a);
-            a = cf_fma(sb, cf{1.0f, -1.0f}, a);
-        }
+    } else if constexpr (4 * K == L) {  // w = -i : w b = (b.y, -b.x): packed adds with a swizzle and a one-lane negation
+        const cf t = b;
+        b = pk_add_pi(a, t);
+        a = pk_add_mi(a, t);
     } else {
         constexpr int m = K * (64 / L);
         constexpr float wr = cos64(m), wi = -sin64(m);
@@ -111,25 +109,25 @@ __device__ __forceinline__ void bfly_const(cf &a, cf &b) {
 }
 
 // one level of the constant-twiddle DFT: butterflies (base + k, base + k + HALF), k < HALF
-template <int R, int HALF, bool MI, int BASE = 0, int K = 0>
+template <int R, int HALF, int BASE = 0, int K = 0>
 __device__ __forceinline__ void dft_const_level(cf *y) {
     if constexpr (BASE < R) {
-        bfly_const<2 * HALF, K, MI>(y[BASE + K], y[BASE + K + HALF]);
-        if constexpr (K + 1 < HALF) dft_const_level<R, HALF, MI, BASE, K + 1>(y);
-        else dft_const_level<R, HALF, MI, BASE + 2 * HALF, 0>(y);
+        bfly_const<2 * HALF, K>(y[BASE + K], y[BASE + K + HALF]);
+        if constexpr (K + 1 < HALF) dft_const_level<R, HALF, BASE, K + 1>(y);
+        else dft_const_level<R, HALF, BASE + 2 * HALF, 0>(y);
     }
 }
-template <int R, int HALF, bool MI>
+template <int R, int HALF>
 __device__ __forceinline__ void dft_const_levels(cf *y) {
     if constexpr (HALF < R) {
-        dft_const_level<R, HALF, MI>(y);
-        dft_const_levels<R, 2 * HALF, MI>(y);
+        dft_const_level<R, HALF>(y);
+        dft_const_levels<R, 2 * HALF>(y);
     }
 }
 
 // R-point DFT (forward, -1 exponent) over x[0], x[S], ..., x[(R-1)S];
 // natural order in and out.  Bit reversal is register renaming only.
-template <int R, int S, bool SKIP = false, bool MI = true>
+template <int R, int S, bool SKIP = false>
 __device__ __forceinline__ void dft_regs(cf *x) {
     if constexpr (SKIP) return;
     static_assert(R >= 2 && R <= 64 && (R & (R - 1)) == 0, "radix must be 2..64");
@@ -137,7 +135,7 @@ __device__ __forceinline__ void dft_regs(cf *x) {
     cf y[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) y[bitrev_c(i, BITS)] = x[i * S];
-    dft_const_levels<R, 1, MI>(y);
+    dft_const_levels<R, 1>(y);
 #pragma unroll
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
@@ -165,12 +163,12 @@ __device__ __forceinline__ void dft_win_level(const cf *x, const cf *wv, cf *y) 
         dft_win_level<R, S, E0, I + 1>(x, wv, y);
     }
 }
-template <int R, int S, int E0, bool MI = true>
+template <int R, int S, int E0>
 __device__ __forceinline__ void dft_regs_win(cf *x, const cf *wv) {
     static_assert(R >= 2 && R <= 64 && (R & (R - 1)) == 0, "radix must be 2..64");
     cf y[R];
     dft_win_level<R, S, E0>(x, wv, y);
-    dft_const_levels<R, 2, MI>(y);
+    dft_const_levels<R, 2>(y);
 #pragma unroll
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
@@ -181,7 +179,7 @@ __device__ __forceinline__ void dft_regs_win(cf *x, const cf *wv) {
 //   minus = 2 a - plus                                  1 pk_fma
 // i.e. 5 packed ops per pair instead of 6 (3 instead of 4 for the untwiddled row 0).
 // SC0: scale applied to row 0 (the other rows carry it in their twiddles), 1 = none.
-template <int R, int S, int TS, bool MI = true>
+template <int R, int S, int TS>
 __device__ __forceinline__ void dft_regs_tw(cf *x, const cf *tw, float sc0) {
     static_assert(R >= 4 && R <= 64 && (R & (R - 1)) == 0, "radix must be 4..64");
     constexpr int BITS = ilog2c(R);
@@ -198,77 +196,9 @@ __device__ __forceinline__ void dft_regs_tw(cf *x, const cf *tw, float sc0) {
         y[bitrev_c(i, BITS)] = plus;
         y[bitrev_c(i + R / 2, BITS)] = cf_fma(a, cf{2.0f, 2.0f}, -plus);
     }
-    dft_const_levels<R, 2, MI>(y);
+    dft_const_levels<R, 2>(y);
 #pragma unroll
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
-}
-
-// ---- the last level in power form (OPT 8388608; fsea_pk_asm.h) ----
-// Where a row only ever leaves as |X|^2 (MAG rows, dB pixels), the last butterfly level of the last pass does not form
-// its two complex outputs: for the pair (y[k], y[k + R/2]) with the constant twiddle W_R^k it forms the planar pairs
-// (x0.re, x1.re) and (x0.im, x1.im) -- two packed ops for w = 1 / -i, four for a general w, against 2 / 3 -- and from
-// them both powers in two packed ops instead of v_mul + v_fmac per bin: one VALU op less per pair with a general
-// twiddle, two with a trivial one.  pp[k S] = (|X_k|^2, |X_{k + R/2}|^2).  x0 is bit-identical to bfly_const's;
-// x1 = a - w b is formed directly (two roundings) instead of 2 a - x0 (three).
-// dc_hi (DC = true, pair 0 only): added to both components of x1 -- the restored offset-binary DC term of bin N/2
-// (FftKernel::epilogue), for the one lane and mode that keep it; zero elsewhere.
-template <int L, int K, bool DC = false>
-__device__ __forceinline__ cf bfly_power(cf a, cf b, float dc_hi = 0.0f) {
-    cf re, im;
-    if constexpr (K == 0) {
-        re = pk_pm_re(a, b);
-        im = pk_pm_im(a, b);
-    } else if constexpr (4 * K == L) {
-        re = pk_pm_re_mi(a, b);
-        im = pk_pm_im_mi(a, b);
-    } else {
-        constexpr int m = K * (64 / L);
-        constexpr float wr = cos64(m), wi = -sin64(m);
-        const cf w = cf{wr, wi};
-        re = pk_pm_re_w(a, b, w);
-        im = pk_pm_im_w(a, b, w);
-    }
-    if constexpr (DC) {
-        re[1] += dc_hi;
-        im[1] += dc_hi;
-    }
-    return cf_fma(re, re, im * im);  // the order of the scalar form: fma(re, re, im * im)
-}
-template <int R, int S, bool DC, int K = 0>
-__device__ __forceinline__ void dft_power_level(const cf *y, cf *pp, float dc_hi) {
-    if constexpr (K < R / 2) {
-        if constexpr (K == 0) pp[0] = bfly_power<R, 0, DC>(y[0], y[R / 2], dc_hi);
-        else pp[K * S] = bfly_power<R, K>(y[K], y[K + R / 2]);
-        dft_power_level<R, S, DC, K + 1>(y, pp, dc_hi);
-    }
-}
-template <int R, int HALF, int STOP, bool MI>
-__device__ __forceinline__ void dft_const_levels_below(cf *y) {
-    if constexpr (HALF < STOP) {
-        dft_const_level<R, HALF, MI>(y);
-        dft_const_levels_below<R, 2 * HALF, STOP, MI>(y);
-    }
-}
-// dft_regs_tw with the last level in power form: x is consumed, pp[k S] (k < R/2) receives the powers
-template <int R, int S, int TS, bool MI = true, bool DC = false>
-__device__ __forceinline__ void dft_regs_tw_pw(const cf *x, const cf *tw, float sc0, cf *pp, float dc_hi = 0.0f) {
-    static_assert(R >= 4 && R <= 64 && (R & (R - 1)) == 0, "radix must be 4..64");
-    constexpr int BITS = ilog2c(R);
-    cf y[R];
-#pragma unroll
-    for (int i = 0; i < R / 2; ++i) {
-        cf a = x[i * S];
-        if (i == 0) {
-            if (sc0 != 1.0f) a = a * cf{sc0, sc0};
-        } else {
-            a = pk_cmul(a, tw[(i - 1) * TS]);
-        }
-        const cf plus = pk_cmul_add(x[(i + R / 2) * S], tw[(i + R / 2 - 1) * TS], a);
-        y[bitrev_c(i, BITS)] = plus;
-        y[bitrev_c(i + R / 2, BITS)] = cf_fma(a, cf{2.0f, 2.0f}, -plus);
-    }
-    dft_const_levels_below<R, 2, R / 2, MI>(y);
-    dft_power_level<R, S, DC>(y, pp, dc_hi);
 }
 
 // The same twiddled DFT with the inter-pass twiddles deferred into the butterfly levels
@@ -347,38 +277,9 @@ enum : int { IN_U8 = 0, IN_F32 = 1, IN_U8_ROT = 2 };  // IN_U8_ROT: launch selec
 template <int N_, int T_, int FPW_, int WPE_, int NP_, int R0_, int R1_, int R2_ = 1, int R3_ = 1,
           bool TWL_ = true, bool TWR_ = true, int ABL_ = 0, int OPT_ = FSEA_DEFAULT_OPT>
 struct FftCfg {
-    // OPT: schedule options (all give identical results):
-    // 1 = the "everyone has read" barrier of an exchange sits right before the next writes into
-    //     the buffer (after the butterflies) instead of right after the reads;
-    // 2 = the reads of an exchange stay one batch (scheduling fence behind them), the waits
-    //     for them become progressive;
-    // 4 = a middle pass fetches all its twiddles from LDS together with the data;
-    // 8 = the twiddle multiply is fused into the first butterfly level (dft_regs_tw; one packed
-    //     op less per pair, rounding differs in the last bit);
-    // 16 = a middle pass that reads 16 bytes per lane (C = 2, P = 32) rotates its lanes inside every
-    //     16-lane block by the block index: the pad shifts each block by one 16-byte slot, which
-    //     puts two lanes of every ds_read_b128 lane group on one slot (8 instead of 4 LDS cycles
-    //     per instruction; scripts/lds_conflicts.py); rotated, the groups are conflict-free;
-    // 32 = the same renumbering for the last pass (and the cross-block form for 8-byte layouts, see
-    //     pass_lane); on where the last pass has that shape (4096 points), worth nothing in time.
-    // 128 = the middle pass's twiddles are deferred into the butterflies (dft_regs_def) and kept in
-    //     registers for the workgroup's lifetime: R/2 pairs per column instead of R-1 LDS reads per frame;
-    // 256 = the +-i butterflies as packed FMAs by (+-1, -+1) instead of packed adds (the round-1 form);
-    // 512 = ticket sizes: the ticket word is waited for behind pass 1's LDS reads, not in front of them;
-    // 64 = the V2 schedule (run_v2): first exchange inside each wavefront, two barriers per frame,
-    //     middle-pass twiddles deferred into the butterflies and kept in registers.
-    // Cache policy: 4096 = row stores nt (where a store writes a whole 128-byte line per frame, st_aux),
-    //     8192 = sc1, 16384 = sc0 (tuning), 32768 = input loads nt.
-    // Product configurations (fsea_configs.h) use the bits above only.  Tuning-library experiments, all measured
-    // and rejected: 1024 = constant higher priority for the younger workgroup of a CU,
-    //     2048 = static unit interleave compiled in (the product chooses per launch: FftArgs::dynamic_units),
-    //     65536 = the two workgroups of a CU alternate priority per frame, 131072 = priority by the pool's average
-    //     progress, 262144 = priority by the partner workgroup's published progress.
+    // OPT: schedule options, names and meanings in fsea_opt.h (all give identical results); the product configurations and what
+    // each one uses: fsea_configs.h.  ABL: measurement-only ablations of the tuning library (abl::..., results wrong by design).
     static constexpr int OPT = OPT_;
-    // ABL: measurement-only ablations (tuning variants, results are wrong by design):
-    // 1 = no output stores, 2 = no LDS exchange / barriers, 4 = no butterflies / twiddles, 8 / 16 / 32 = V2-schedule
-    // ablations, 64 = no per-frame loads, 128 = no magnitude arithmetic / no logarithm, 256 = rows stored 16 bytes per
-    // lane (misplaced), 512 = frame loaded 16 bytes per lane (misplaced).  Always 0 in the product configurations.
     static constexpr int ABL = ABL_;
     static constexpr int N = N_, T = T_, FPW = FPW_, NP = NP_;
     static constexpr int WPE = WPE_;  // waves per SIMD the register budget must allow
@@ -687,7 +588,7 @@ __device__ __forceinline__ cf turn_phasor_f32(double turns) {
 template <class Cfg, int IN, int MODE_T = -1, bool ROT = false, bool RUNS = false, int WIN = 0>
 struct FftKernel {
     static_assert(!ROT || IN == IN_U8, "the fused frequency shift is a u8-input path");
-    static_assert(WIN == 0 || (IN == IN_U8 && !ROT && Cfg::TWR && (Cfg::OPT & (64 | 1048576 | 8388608)) == 0 && Cfg::P >= 8),
+    static_assert(WIN == 0 || (IN == IN_U8 && !ROT && Cfg::TWR && (Cfg::OPT & opt::TUNE_ONLY) == 0 && Cfg::P >= 8),
                   "the windowed kernels: u8 input, V1 schedule, register-resident (prescaled) last-pass twiddles");
     static_assert(!RUNS || (IN == IN_U8 && !ROT && Cfg::FPW == 1 && (Cfg::R(0) % 2) == 0), "half-overlap runs: u8 input, one frame per workgroup");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
@@ -701,16 +602,11 @@ struct FftKernel {
     static constexpr float SC = (IN == IN_U8) ? (1.0f / 256.0f) : 1.0f;
     static constexpr bool PRESCALED = Cfg::TWR && (IN == IN_U8);
     using Raw = RawRow<IN, C0>;
-    // The barrier that separates a pass's LDS reads from the next writes into the same buffer
-    // may sit right before those writes (after the butterflies) instead of right after the
-    // reads: the reads' latency overlaps the butterflies and the waves' skew is absorbed by them.
-    static constexpr bool LAZY_SYNC = (Cfg::OPT & 1) != 0;
-    static constexpr bool BATCH_READS = (Cfg::OPT & 2) != 0;
-    static constexpr bool TW_HOIST = (Cfg::OPT & 4) != 0;
-    static constexpr bool TW_FUSE = (Cfg::OPT & 8) != 0 && (Cfg::ABL & 4) == 0;
-    // OPT 4096 / 8192 / 16384: cache policy of the f32 row stores (measurement variants): nt (streaming),
-    // sc1 (write through the XCD's L2 and drop the line), sc0 sc1
-    static constexpr int ST_AUX = ((Cfg::OPT & 4096) ? 2 : 0) | ((Cfg::OPT & 8192) ? 16 : 0) | ((Cfg::OPT & 16384) ? 1 : 0);
+    static constexpr bool BATCH_READS = (Cfg::OPT & opt::BATCH_READS) != 0;
+    static constexpr bool TW_HOIST = (Cfg::OPT & opt::TW_HOIST) != 0;
+    static constexpr bool TW_FUSE = (Cfg::OPT & opt::TW_FUSE) != 0 && (Cfg::ABL & abl::NO_FLOPS) == 0;
+    // opt::ST_NT: the row stores are streaming (nt) -- where one store covers a whole line, st_aux() below
+    static constexpr int ST_AUX = (Cfg::OPT & opt::ST_NT) ? 2 : 0;
     // One store instruction writes, per frame, the T lanes' CL adjacent elements: T*CL*size bytes in a row.  A
     // streaming (nt) store of less than a 128-byte line reaches HBM as a partial line -- measured write traffic
     // (WRITE_SIZE) of the u8 pixel rows 1.2x (1024 points, 32-byte pieces) to 2.4x (128 points, 16-byte pieces) the
@@ -725,19 +621,12 @@ struct FftKernel {
     template <int ELEM_BYTES>
     static constexpr int st_aux() { return (T * CL * ELEM_BYTES >= 128 && CL * ELEM_BYTES <= 16) ? ST_AUX : (ST_AUX & ~2); }
     // OPT 32768: the input loads are streaming (nt) as well
-    static constexpr int LD_AUX = (Cfg::OPT & 32768) ? 2 : 0;
-    static constexpr bool DEFER = (Cfg::OPT & 128) != 0 && NP == 3;
-    static constexpr bool TK_LATE = (Cfg::OPT & 512) != 0 && NP >= 3 && !ONE_WAVE && (Cfg::ABL & 2) == 0;
-    static constexpr bool MI = (Cfg::OPT & 256) == 0;  // OPT 256: the +-i butterflies as packed FMAs by (+-1, -+1) (round-1 form)
-    // OPT 8388608: the last butterfly level in power form (dft_regs_tw_pw) in the kernels whose rows are powers only:
-    // the compile-time MAG / DB10 / DB5 kernels of the V1 schedule with register-resident, fused last-pass twiddles
-    static constexpr bool PW = (Cfg::OPT & 8388608) != 0 && (Cfg::OPT & (64 | 1048576)) == 0 && Cfg::TWR && (Cfg::OPT & 8) != 0 &&
-                               Cfg::ABL == 0 && RL >= 4 &&
-                               (MODE_T == MODE_MAG || MODE_T == MODE_DB10_U8 || MODE_T == MODE_DB5_U8_DCFIX);
-    static constexpr bool PX_PACK = (Cfg::OPT & 2097152) != 0;   // pixel epilogue: v_trunc + v_cvt_pk_u8_f32
-    static constexpr bool PX_BIAS = (Cfg::OPT & 4194304) != 0;   // ... without the v_trunc (biased round-to-nearest)
-    static constexpr bool LANE_ROT = (Cfg::OPT & 16) != 0;       // middle passes
-    static constexpr bool LANE_ROT_LAST = (Cfg::OPT & 32) != 0;  // the last pass as well
+    static constexpr int LD_AUX = (Cfg::OPT & opt::LD_NT) ? 2 : 0;
+    static constexpr bool DEFER = (Cfg::OPT & opt::DEFER) != 0 && NP == 3;
+    static constexpr bool PX_PACK = (Cfg::OPT & opt::PX_PACK) != 0;   // pixel epilogue: v_trunc + v_cvt_pk_u8_f32
+    static constexpr bool PX_BIAS = (Cfg::OPT & opt::PX_BIAS) != 0;   // ... without the v_trunc (biased round-to-nearest)
+    static constexpr bool LANE_ROT = (Cfg::OPT & opt::LANE_ROT) != 0;       // middle passes
+    static constexpr bool LANE_ROT_LAST = (Cfg::OPT & opt::LANE_ROT_LAST) != 0;  // the last pass as well
     // Which frame-lane a physical lane works as in pass I >= 1.  Any bijection is valid: passes meet
     // only through LDS, at logical addresses.  Two layouts need one (scripts/lds_conflicts.py):
     // * 16 bytes per lane (C = 2, P = 32): the pad shifts each 16-lane block by one 16-byte slot and
@@ -768,7 +657,7 @@ struct FftKernel {
     // a single wavefront no s_barrier is needed: LDS operations of one wave
     // execute in order.
     static __device__ __forceinline__ void frame_sync() {
-        if constexpr (Cfg::ABL & 2) {
+        if constexpr (Cfg::ABL & abl::NO_LDS) {
             return;
         } else if constexpr (ONE_WAVE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -779,13 +668,6 @@ struct FftKernel {
         }
     }
 
-    // the compiler would otherwise hoist the s_barrier above the butterflies (VALU work is not
-    // ordered against it), which is the eager placement again
-    static __device__ __forceinline__ void lazy_sync() {
-        if constexpr (!ONE_WAVE) __builtin_amdgcn_sched_barrier(0);
-        frame_sync();
-    }
-
     static constexpr uint32_t IN_BPS = (IN == IN_U8) ? 2 : 8;  // input bytes per complex sample
 
     // voff: this lane's byte offset inside the unit's window (slot * hop + C0 t samples)
@@ -794,17 +676,6 @@ struct FftKernel {
     template <int RLO, int RHI>
     static __device__ __forceinline__ void load_raw_rows(rsrc_t rs, uint32_t voff, Raw *raw) {
         constexpr int STRIDE = N / R0;
-        // ABL 512 (measurement only, wrong samples per lane): the frame's bytes fetched 16 per lane, 1 KiB
-        // runs per wave instruction -- what a pass-0 layout with 8 adjacent samples per lane would issue
-        if constexpr ((Cfg::ABL & 512) != 0 && IN == IN_U8 && C0 == 2 && R0 % 4 == 0 && FPW == 1 && RLO == 0 && RHI == R0) {
-#pragma unroll
-            for (int r = 0; r < R0 / 4; ++r) {
-                const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff * 4u, (uint32_t)(r * 16 * T), LD_AUX);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) raw[4 * r + i].w = q[i];
-            }
-            return;
-        }
 #pragma unroll
         for (int r = RLO; r < RHI; ++r) {
             const uint32_t soff = (uint32_t)(r * STRIDE) * IN_BPS;
@@ -853,7 +724,7 @@ struct FftKernel {
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                if constexpr (Cfg::ABL & 4) v[r * C + c] += w[c];
+                if constexpr (Cfg::ABL & abl::NO_FLOPS) v[r * C + c] += w[c];
                 else v[r * C + c] = pk_cmul(v[r * C + c], w[c]);
             }
         }
@@ -866,7 +737,7 @@ struct FftKernel {
     template <int I>
     static __device__ __forceinline__ void lds_write(cf *lds, const cf *v, int t) {
         constexpr int R = Cfg::R(I), C = Cfg::C(I), Ns = Cfg::Ns(I);
-        if constexpr (Cfg::ABL & 2) {
+        if constexpr (Cfg::ABL & abl::NO_LDS) {
             return;
         } else if constexpr (Ns == 1 && (R % 2) == 0) {
             // column c owns R contiguous outputs at (C t + c) R: the thread's P
@@ -913,7 +784,7 @@ struct FftKernel {
     static __device__ __forceinline__ void lds_read(const cf *lds, cf *v, int t) {
         constexpr int R = Cfg::R(I), C = Cfg::C(I);
         constexpr int STRIDE = N / R;
-        if constexpr (Cfg::ABL & 2) {
+        if constexpr (Cfg::ABL & abl::NO_LDS) {
             return;
         } else if constexpr (STRIDE % P == 0) {
             const cf *base = lds + Cfg::pad(C * t);
@@ -926,23 +797,17 @@ struct FftKernel {
     }
 
     // middle pass I (1 <= I < LAST): read, twiddle, DFT, write back
-    // issued(): called once, right behind the LDS reads of pass 1 (OPT 512: the ticket and the next
-    // unit's loads are handled there, so that the reads are in flight before the ticket is waited for)
-    struct NoHook {
-        __device__ __forceinline__ void operator()() const {}
-    };
-    template <int I, class Hook = NoHook>
+    template <int I>
     static __device__ __forceinline__ void middle_pass(cf *lds, const cf *lds_all, cf *v, const FftArgs &a, int t0,
-                                                       const cf *tw_res = nullptr, Hook &&issued = Hook()) {
+                                                       const cf *tw_res = nullptr) {
         if constexpr (I < LAST) {
             constexpr int R = Cfg::R(I), C = Cfg::C(I);
             const int t = pass_lane<I>(t0);
             const cf *tw = Cfg::TWL ? (lds_all + Cfg::lds_tw_off(I)) : a.tw[I];
             if constexpr (DEFER) {
                 lds_read<I>(lds, v, t);
-                if constexpr (I == 1) issued();
                 after_reads();
-                if constexpr (!LAZY_SYNC) frame_sync();
+                frame_sync();
 #pragma unroll
                 for (int c = 0; c < C; ++c) dft_regs_def<R, C, 1>(v + c, tw_res + c * (R / 2));
             } else if constexpr (TW_HOIST && (Cfg::Ns(I) % C == 0)) {
@@ -952,12 +817,11 @@ struct FftKernel {
 #pragma unroll
                 for (int r = 1; r < R; ++r) ld_c<C>(tw + (r - 1) * Ns + k0, w + (r - 1) * C);
                 lds_read<I>(lds, v, t);
-                if constexpr (I == 1) issued();
                 after_reads();
-                if constexpr (!LAZY_SYNC) frame_sync();
+                frame_sync();
                 if constexpr (TW_FUSE) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) dft_regs_tw<R, C, C, MI>(v + c, w + c, 1.0f);
+                    for (int c = 0; c < C; ++c) dft_regs_tw<R, C, C>(v + c, w + c, 1.0f);
                 } else {
 #pragma unroll
                     for (int r = 1; r < R; ++r) {
@@ -967,19 +831,17 @@ struct FftKernel {
                 }
             } else {
                 lds_read<I>(lds, v, t);
-                if constexpr (I == 1) issued();
                 after_reads();
-                if constexpr (!LAZY_SYNC) frame_sync();  // everyone has read before anyone overwrites
+                frame_sync();  // everyone has read before anyone overwrites
                 apply_twiddles<I>(v, tw, t);
             }
             if constexpr (!DEFER && !(TW_FUSE && TW_HOIST && (Cfg::Ns(I) % C == 0))) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & 4) != 0, MI>(v + c);
+                for (int c = 0; c < C; ++c) dft_regs<R, C, (Cfg::ABL & abl::NO_FLOPS) != 0>(v + c);
             }
-            if constexpr (LAZY_SYNC) lazy_sync();  // same barrier, after this wave's butterflies
             lds_write<I>(lds, v, t);
             frame_sync();
-            middle_pass<I + 1>(lds, lds_all, v, a, t0, tw_res);  // further middle passes: no hook
+            middle_pass<I + 1>(lds, lds_all, v, a, t0, tw_res);
         }
     }
 
@@ -989,25 +851,13 @@ struct FftKernel {
 
     // fused epilogue for the row held as v[r*CL + c] = bin CL t + c + r NsL.
     // out: window of this unit's rows; lane_elem = slot * N + CL * t (first bin of this lane)
-    // |v[r CL + c]|^2, or -- PW -- the power the last level left in pp[(r mod RL/2) CL + c] (fsea::dft_power_level)
-    static __device__ __forceinline__ float bin_power(const cf *v, [[maybe_unused]] const cf *pp, int r, int c) {
-        if constexpr (PW) {
-            return pp[(r % (RL / 2)) * CL + c][r / (RL / 2)];
-        } else {
-            const cf z = v[r * CL + c];
-            return __builtin_fmaf(z[0], z[0], z[1] * z[1]);
-        }
+    // |v[r CL + c]|^2
+    static __device__ __forceinline__ float bin_power(const cf *v, int r, int c) {
+        const cf z = v[r * CL + c];
+        return __builtin_fmaf(z[0], z[0], z[1] * z[1]);
     }
-    // the restored DC term of bin N/2 for the lane and mode that keep it (see epilogue), else 0: what PW kernels hand to
-    // the power form of the last level, which has no complex bin to add it to afterwards
-    static __device__ __forceinline__ float dc_restore(int mode, int t) {
-        const bool patched = (mode == MODE_MAG) || (mode == MODE_DB5_U8_DCFIX);
-        return (IN == IN_U8 && !patched && t == 0) ? (PRESCALED ? 0.5f : 128.0f) * (float)N : 0.0f;
-    }
-    static constexpr bool PW_DC = PW && IN == IN_U8 && MODE_T == MODE_DB10_U8;
 
-    static __device__ __forceinline__ void epilogue(int mode, rsrc_t out, uint32_t lane_elem, cf *v, int t,
-                                                    [[maybe_unused]] const cf *pp = nullptr) {
+    static __device__ __forceinline__ void epilogue(int mode, rsrc_t out, uint32_t lane_elem, cf *v, int t) {
         constexpr float SE = PRESCALED ? 1.0f : SC;  // scale still to apply to re / im
         constexpr float SE2 = SE * SE;
         const bool patched = (mode == MODE_MAG) || (mode == MODE_DB5_U8_DCFIX);
@@ -1015,7 +865,7 @@ struct FftKernel {
         // (-1)^n centring moves to bin N/2 exactly: 0.5 N (1 + i).  The kernel
         // transforms (u - 128) instead and restores that bin analytically in
         // the modes that keep it.
-        if (!PW && WIN == 0 && IN == IN_U8 && !patched && t == 0) {
+        if (WIN == 0 && IN == IN_U8 && !patched && t == 0) {
             const float dc = (PRESCALED ? 0.5f : 128.0f) * (float)N;
             v[(RL / 2) * CL] += cf{dc, dc};
         }
@@ -1032,7 +882,6 @@ struct FftKernel {
             // 10*log10(p + 1e-20) * s = (10 s log10(2)) * log2(p + 1e-20)
             const float kdb = (mode == MODE_DB10_U8 ? 100.0f : 50.0f) * 0.30102999566398120f;
             const uint32_t voff = lane_elem;
-            [[maybe_unused]] uint8_t wide_px[4];
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
                 const uint32_t soff = (uint32_t)(r * NsL);
@@ -1040,7 +889,7 @@ struct FftKernel {
                 [[maybe_unused]] uint32_t pxw[(CL + 3) / 4] = {};
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
-                    float p = bin_power(v, pp, r, c);
+                    float p = bin_power(v, r, c);
                     if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
                     // The reference's "+ 1e-20" only keeps log10 finite: in f32 it changes p by less than
                     // half an ulp whenever the pixel is not clamped to 0 anyway (p > 1e-13), and for
@@ -1055,11 +904,11 @@ struct FftKernel {
                         float d;
                         if constexpr (PX_BIAS) d = __builtin_fmaf(kdb, __builtin_amdgcn_logf(p), -0.49999997f);
                         else d = trunc_f32(kdb * __builtin_amdgcn_logf(p));
-                        if constexpr (Cfg::ABL & 128) d = kdb * p;
+                        if constexpr (Cfg::ABL & abl::NO_EPILOGUE_MATH) d = kdb * p;
                         pxw[c / 4] = cvt_pk_u8(d, (uint32_t)(c & 3), pxw[c / 4]);
                     } else {
                         float d = kdb * __builtin_amdgcn_logf(p);
-                        if constexpr (Cfg::ABL & 128) d = kdb * p;  // ABL 128 (measurement only): no logarithm
+                        if constexpr (Cfg::ABL & abl::NO_EPILOGUE_MATH) d = kdb * p;  // ABL 128 (measurement only): no logarithm
                         int q = (int)d;  // truncation toward zero, as the C cast in the reference
                         q = q < 0 ? 0 : (q > 255 ? 255 : q);
                         px[c] = (uint8_t)q;
@@ -1069,15 +918,8 @@ struct FftKernel {
 #pragma unroll
                     for (int c = 0; c < CL; ++c) px[c] = (uint8_t)(pxw[c / 4] >> (8 * (c & 3)));  // (only the patched lanes' byte stores read these)
                 }
-                if constexpr (Cfg::ABL & 1) {
+                if constexpr (Cfg::ABL & abl::NO_STORES) {
                     if (px[0] == 255 && px[CL - 1] == 254 && v[0][0] == -1.0f) bst<CL>(out, voff, soff, px);  // (practically) never
-                } else if constexpr ((Cfg::ABL & 256) != 0 && CL <= 2 && (RL * CL) % 4 == 0) {
-                    // ABL 256 (measurement only, pixels land in the wrong places): four pixels per dword store
-                    constexpr int PER = 4 / CL;  // rows per dword
-#pragma unroll
-                    for (int c = 0; c < CL; ++c) wide_px[(r % PER) * CL + c] = px[c];
-                    if (r % PER == PER - 1)
-                        bst<4, ST_AUX>(out, lane_elem + (uint32_t)((4 - CL) * t), (uint32_t)((r / PER) * 4 * T), wide_px);
                 } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
                     for (int c = 1; c < CL; ++c) bst<1>(out, voff + c, soff, px + c);
@@ -1096,43 +938,35 @@ struct FftKernel {
         } else if (mode == MODE_DB_F32) {
             // two loops, one transcendental each: written as `mode == MODE_DB_F32 ? log : sqrt` per element the compiler
             // turns the uniform test into v_log_f32 + v_sqrt_f32 + v_cndmask for every bin
-            f32_rows<true>(patched, out, lane_elem, v, t, pp);
+            f32_rows<true>(patched, out, lane_elem, v, t);
         } else {
-            f32_rows<false>(patched, out, lane_elem, v, t, pp);
+            f32_rows<false>(patched, out, lane_elem, v, t);
         }
     }
 
     template <bool LOG>
-    static __device__ __forceinline__ void f32_rows(bool patched, rsrc_t out, uint32_t lane_elem, cf *v, int t,
-                                                    [[maybe_unused]] const cf *pp) {
+    static __device__ __forceinline__ void f32_rows(bool patched, rsrc_t out, uint32_t lane_elem, cf *v, int t) {
         constexpr float SE = PRESCALED ? 1.0f : SC;
         constexpr float SE2 = SE * SE;
         const uint32_t voff = lane_elem * 4u;
-        [[maybe_unused]] float wide[4];
 #pragma unroll
         for (int r = 0; r < RL; ++r) {
             const uint32_t soff = (uint32_t)(r * NsL) * 4u;
             float m[CL];
 #pragma unroll
             for (int c = 0; c < CL; ++c) {
-                float p = bin_power(v, pp, r, c);
+                float p = bin_power(v, r, c);
                 if constexpr (!PRESCALED && IN == IN_U8) p *= SE2;
                 if constexpr (LOG) {
                     m[c] = (10.0f * 0.30102999566398120f) * __builtin_amdgcn_logf(p + 1.0e-20f);
-                } else if constexpr (Cfg::ABL & 128) {  // ABL 128 (measurement only): no magnitude arithmetic
+                } else if constexpr (Cfg::ABL & abl::NO_EPILOGUE_MATH) {  // ABL 128 (measurement only): no magnitude arithmetic
                     m[c] = v[r * CL + c][0];
                 } else {
                     m[c] = __builtin_amdgcn_sqrtf(p);
                 }
             }
-            if constexpr (Cfg::ABL & 1) {
+            if constexpr (Cfg::ABL & abl::NO_STORES) {
                 if (m[0] == -1.0f) bst<CL>(out, voff, soff, m);  // never true: sqrt >= 0
-            } else if constexpr ((Cfg::ABL & 256) != 0 && CL == 1 && RL % 4 == 0) {
-                // ABL 256 (measurement only, bins land in the wrong places): the row stored 16 bytes per
-                // lane, 1 KiB runs per wave instruction -- what a last pass with 4 adjacent bins per lane
-                // would issue.  The values wait in wide[] until four are there.
-                wide[r & 3] = m[0];
-                if ((r & 3) == 3) bst<4, ST_AUX>(out, (lane_elem + 3u * (uint32_t)t) * 4u, (uint32_t)((r >> 2) * 4 * T) * 4u, wide);
             } else if (patched && r == RL / 2 && t == 0) {
 #pragma unroll
                 for (int c = 1; c < CL; ++c) bst<1>(out, voff + 4 * c, soff, m + c);
@@ -1161,7 +995,7 @@ struct FftKernel {
     // Sizes whose frames live inside one wavefront have no barrier to publish a ticket with and
     // thousands of independent waves to average over: they keep a static interleave
     // (unit = blockIdx + k * gridDim); the ticket scheme is for the multi-wave sizes.
-    static constexpr bool DYNAMIC = !ONE_WAVE && (Cfg::OPT & 2048) == 0;  // OPT 2048 (tuning): static interleave at every size
+    static constexpr bool DYNAMIC = !ONE_WAVE;
     static constexpr unsigned POOLS = 8;
     static constexpr unsigned NO_UNIT = 0xffffffffu;
 
@@ -1176,15 +1010,16 @@ struct FftKernel {
         }
     };
 
-    static constexpr bool V2 = (Cfg::OPT & 64) != 0;
-    // what a launch does with FftArgs::ctr (host side: which launches need a ticket-counter slot, fsea_api.hip)
-    static constexpr int counters_used() {
-        if ((Cfg::OPT & 1048576) != 0) return 0;                     // W64: one wave per frame, static interleave
-        if (V2 || (Cfg::OPT & 262144) != 0) return 2;
-        return DYNAMIC ? 1 : 0;
-    }
-
-    static constexpr bool W64 = (Cfg::OPT & 1048576) != 0;
+    // The two schedules of the tuning library (fsea_fft_tune_members.h); a product build has neither.
+#ifdef FSEA_TUNE
+    static constexpr bool V2 = (Cfg::OPT & opt::V2) != 0, W64 = (Cfg::OPT & opt::W64) != 0;
+#else
+    static constexpr bool V2 = false, W64 = false;
+    static_assert((Cfg::OPT & opt::TUNE_ONLY) == 0 && Cfg::ABL == 0, "tuning-only option or ablation in a product build");
+#endif
+    // what a launch does with FftArgs::ctr (host side: which launches need a ticket-counter slot, fsea_api.hip):
+    // 0 = nothing, 1 = ticket pools when FftArgs::dynamic_units, 2 = ticket pools always (V2)
+    static constexpr int counters_used() { return W64 ? 0 : (V2 ? 2 : (DYNAMIC ? 1 : 0)); }
 
     // ---- taper window (WIN kernels) ----
     static constexpr int WPAIRS = WIN ? P / 2 : 1;
@@ -1215,441 +1050,23 @@ struct FftKernel {
     template <int C = 0>
     static __device__ __forceinline__ void pass0_windowed(cf *v, const cf *wv) {
         if constexpr (C < C0) {
-            dft_regs_win<R0, C0, C, MI>(v + C, wv);
+            dft_regs_win<R0, C0, C>(v + C, wv);
             pass0_windowed<C + 1>(v, wv);
         }
     }
 
+#ifdef FSEA_TUNE
+#include "fsea_fft_tune_members.h"
     static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) {
         if constexpr (W64) run_w64(a, lds_all);
         else if constexpr (V2) run_v2(a, lds_all);
         else run_v1(a, lds_all);
     }
-
-    // -----------------------------------------------------------------------------------------
-    // W64 schedule (OPT 1048576): N = 64 x 64, one wavefront per frame, 64 points per lane, ONE exchange
-    // through LDS and no s_barrier at all.
-    //
-    // Sample n = 64 n1 + n2, bin k = k1 + 64 k2.  Pass 0: lane n2 transforms x[64 n1 + n2] over n1 (64 points, constant
-    // twiddles) -> y[k1]; exchange: element (k1, n2) goes from lane n2 to lane k1; pass 1: lane k1 transforms over n2 with
-    // the twiddles W_N^{n2 k1} deferred into the butterflies (dft_regs_def; 32 register pairs per lane, resident) -> k2.
-    //   * (-1)^n = (-1)^{n2} is a shift of the spectrum by N/2 bins = of k2 by 32: nothing is negated, row r of the
-    //     last pass is bin k1 + 64 (r ^ 32) -- register renaming.
-    //   * Loads.  A lane holding one sample per row would load 2 bytes at a time.  Instead lane L loads the dword
-    //     sigma(L) + 64 j (j < 32): 256 contiguous bytes per wave instruction, two adjacent samples (n2 = 2d, 2d + 1) of
-    //     row n1 = 2j (+1 in lanes 32-63: sigma(L + 32) = sigma(L) + 32).  Lanes L and L + 32 therefore hold the same
-    //     two n2 with complementary n1, and ONE v_permlane32_swap_b32 per pair of rows hands each the other's half:
-    //     A = perm(keep / send), B = perm(send / keep), swap(A, B) -> A = rows (2j, 2j'), B = rows (2j + 1, 2j' + 1)
-    //     of the lane's own n2, the same registers in every lane.  Three VALU ops per four samples.
-    //   * Which n2 a lane ends up with is free (passes meet in LDS at logical addresses); sigma and the kept half are
-    //     chosen so that the 16 lanes of every ds_write_b64 lane group hold n2 that differ mod 16 (conflict-free):
-    //     n2(L) = 2 pi(L & 31) + ((L >> 5) ^ (L & 1)), pi(t) = (t & 16) + ((t & 15) >> 1) + 8 (t & 1).
-    //   * LDS: element (k1, n2) at k1 * 66 + n2 (complex units; 16 bytes of pad per row): 64 ds_write_b64 whose lanes
-    //     cover one 512-byte row each, 32 ds_read_b128 of the lane's own row (row pitch 33 x 16 bytes: conflict-free).
-    //   * Pixel rows (u8 modes): a lane's 64 pixels are bins k1 + 64 r, one byte each.  Four rows are packed into a dword
-    //     by v_cvt_pk_u8_f32 (conversion and packing in one op), transposed 4 x 4 inside each quad of lanes (two
-    //     v_mov_b32_dpp quad_perm + two v_perm_b32) and stored as dwords: lane 4m + i writes bins 4m .. 4m+3 of row
-    //     4q + i, the wave 256 contiguous bytes per instruction, 16 stores per frame.
-    // -----------------------------------------------------------------------------------------
-    static __device__ __forceinline__ void run_w64(const FftArgs &a, cf *lds) {
-        static_assert(!W64 || (N == 4096 && T == 64 && FPW == 1 && NP == 2 && R0 == 64 && RL == 64), "W64 is the 64 x 64 layout");
-        static_assert(!W64 || (IN == IN_U8 && !ROT), "W64 serves the u8 kernels");
-        static_assert(!W64 || (!Cfg::TWL && !Cfg::TWR), "W64 keeps its (deferred) twiddles in registers: no table block in LDS");
-        constexpr int ROW = 66;  // LDS row pitch in complex units
-        const int L = threadIdx.x;
-        const unsigned b = blockIdx.x;
-        const size_t n_units = a.n_frames;
-        const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
-        const uint32_t xormask = (MODE_T >= 0) ? 0u : a.xormask;
-        const uint32_t esz = elem_bytes(mode);
-        const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
-        const bool tiled = a.tile_rows != 0;
-        const size_t total_out = (size_t)esz * (tiled ? a.out_span : a.n_frames * (size_t)N);
-        auto row_elem = [&](size_t f) -> size_t {
-            if (!tiled) return f * (size_t)N;
-            const uint32_t k = (uint32_t)f / a.tile_rows, y = (uint32_t)f - k * a.tile_rows;
-            return (size_t)y * a.pitch_row + (size_t)k * a.pitch_tile;
-        };
-        // pass-0 identity of this lane
-        const int t5 = L & 31, odd = L & 1, hi = L >> 5;
-        const int pi = (t5 & 16) + ((t5 & 15) >> 1) + 8 * odd;
-        const int n2 = 2 * pi + (hi ^ odd);
-        const uint32_t in_voff = 4u * (uint32_t)(pi + 32 * hi);
-        const uint32_t sel_a = odd ? 0x07060302u : 0x05040100u;  // the half (sample) that ends up in A: c = L & 1
-        const uint32_t sel_b = odd ? 0x05040100u : 0x07060302u;
-        // this lane's deferred twiddles of the last pass: row k1 = L of the [64][32] table (build_deferred_table)
-        cf twd[RL / 2];
-        ld_c<RL / 2>(a.tw_def + (size_t)L * (RL / 2), twd);
-
-        auto load_frame = [&](size_t u, uint32_t *raw) {
-            const rsrc_t rs = buffer_window(a.in, (size_t)IN_BPS * u * a.hop, u < n_units ? total_in : 0);
-#pragma unroll
-            for (int j = 0; j < 32; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, in_voff, (uint32_t)(256 * j), LD_AUX);
-        };
-        size_t u = b;
-        uint32_t raw[32];
-        load_frame(u, raw);
-        // the grid size lives in a VGPR: with the 64-point DFT's constants the SGPR file is full, and a gridDim.x re-read
-        // from the dispatch packet (s_load_dword) inside the loop is waited for with lgkmcnt(0) -- together with every
-        // LDS write in flight
-        unsigned grid_v = gridDim.x;
-#if defined(__AMDGCN__)
-        asm volatile("" : "+v"(grid_v));
+#else
+    static __device__ __forceinline__ void run(const FftArgs &a, cf *lds_all) { run_v1(a, lds_all); }
 #endif
-        cf *const wr = lds + n2;               // + ROW k1
-        const cf *const rd = lds + ROW * L;    // + n2
-
-        while (u < n_units) {
-            cf v[64];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t wa = byte_perm(raw[j + 16], raw[j], sel_a);
-                uint32_t wb = byte_perm(raw[j + 16], raw[j], sel_b);
-                lane_swap32(wa, wb);
-                wa ^= xormask;
-                wb ^= xormask;
-                v[2 * j] = cf{s8f(wa, 0), s8f(wa, 1)};
-                v[2 * j + 32] = cf{s8f(wa, 2), s8f(wa, 3)};
-                v[2 * j + 1] = cf{s8f(wb, 0), s8f(wb, 1)};
-                v[2 * j + 33] = cf{s8f(wb, 2), s8f(wb, 3)};
-            }
-            dft_regs<64, 1, (Cfg::ABL & 4) != 0, MI>(v);
-            frame_sync();  // the previous frame's reads precede these writes
-            if constexpr ((Cfg::ABL & 2) == 0) {
-#pragma unroll
-                for (int k1 = 0; k1 < 64; ++k1) wr[ROW * k1] = v[k1];
-            }
-            frame_sync();
-            const size_t un = u + __builtin_amdgcn_readfirstlane(grid_v);
-            if constexpr ((Cfg::ABL & 64) == 0) load_frame(un, raw);
-            if constexpr ((Cfg::ABL & 2) == 0) {
-                // the first butterflies of pass 1 pair elements j and j + 32: fetched in that order
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    ld_c<2>(rd + 2 * q, v + 2 * q);
-                    ld_c<2>(rd + 2 * q + 32, v + 2 * q + 32);
-                }
-            }
-            after_reads();
-            if constexpr ((Cfg::ABL & 4) == 0) dft_regs_def<64, 1, 1>(v, twd);
-            cf w[64];  // centred order: row r = bin L + 64 r
-#pragma unroll
-            for (int r = 0; r < 64; ++r) w[r] = v[r ^ 32];
-            const rsrc_t out = buffer_window(a.out, (size_t)esz * row_elem(u), total_out);
-            if (mode == MODE_DB10_U8 || mode == MODE_DB5_U8_DCFIX) pixels_w64(mode, out, w, L);
-            else epilogue(mode, out, (uint32_t)L, w, L);
-            u = un;
-        }
-    }
-
-    static __device__ __forceinline__ void pixels_w64(int mode, rsrc_t out, cf *w, int L) {
-        const bool patched = (mode == MODE_DB5_U8_DCFIX);
-        if (!patched && L == 0) w[32] += cf{128.0f * (float)N, 128.0f * (float)N};  // DC of the offset-binary samples (see epilogue)
-        const float kdb = (mode == MODE_DB10_U8 ? 100.0f : 50.0f) * 0.30102999566398120f;
-        const float koff = -16.0f * kdb;  // log2 of the 1/256^2 the integer-unit power still carries
-        const uint32_t sel1 = (L & 1) ? 0x03070105u : 0x06020400u;
-        const uint32_t sel2 = (L & 2) ? 0x03020706u : 0x05040100u;
-        const uint32_t voff = (uint32_t)((L & 3) * 64 + (L & ~3));
-        uint32_t left = 0;  // DB5: the pixel of bin N/2 - 1 (row 31, lane 63), copied over bin N/2 (row 32, lane 0)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            uint32_t px = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const cf z = w[4 * q + i];
-                const float p = __builtin_fmaf(z[0], z[0], z[1] * z[1]);
-                float d = __builtin_fmaf(kdb, __builtin_amdgcn_logf(p), PX_BIAS ? koff - 0.49999997f : koff);
-                if constexpr (Cfg::ABL & 128) d = kdb * p;
-                px = cvt_pk_u8(PX_BIAS ? d : trunc_f32(d), (uint32_t)i, px);  // truncation toward zero, then saturation: the reference's cast + clamp
-            }
-            const uint32_t u1 = byte_perm(quad_xor1(px), px, sel1);
-            uint32_t rows = byte_perm(quad_xor2(u1), u1, sel2);  // lane 4m + i: bins 4m .. 4m + 3 of row 4q + i
-            if (q == 7) left = read_lane(rows, 63) >> 24;
-            if (q == 8 && patched && L == 0) rows = (rows & 0xffffff00u) | left;
-            if constexpr (Cfg::ABL & 1) {
-                if (rows == 0x01020304u && w[0][0] == -1.0f) __builtin_amdgcn_raw_buffer_store_b32(rows, out, voff, (uint32_t)(256 * q), ST_AUX);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b32(rows, out, voff, (uint32_t)(256 * q), ST_AUX);
-            }
-        }
-    }
-
-    // -----------------------------------------------------------------------------------------
-    // V2 schedule for frames spread over several wavefronts (three passes RA x RB x RC).
-    //
-    // Sample index n = a N/RA + b RC + c, bin k = ka + RA kb + RA RB kc:
-    //   pass 0 sums over a (-> ka), twiddle W_{RA RB}^{b ka}, pass 1 over b (-> kb), twiddle
-    //   W_N^{c (ka + RA kb)}, pass 2 over c (-> kc).
-    // Only the bits a lane holds in registers are forced (a, b, c in turn); which of the other
-    // bits are lane bits and which are wave bits is free.  V1 takes them in Stockham order, which
-    // makes both exchanges cross-wave: two s_barriers each.  Here the wave bits of passes 0 and 1
-    // are the top bits of c, so the first exchange (ka <-> b) stays inside a wavefront -- LDS
-    // operations of one wave execute in order, no barrier -- and only the second one crosses
-    // waves.  Every element of that second exchange is read by exactly one wave, so the buffer
-    // is a partition S_w by reading wave; once wave w has read its S_w nobody else touches it
-    // until the next cross-wave write, and w runs its own first exchange of the next frame in
-    // it.  Per frame: [pass 0] A-write A-read [pass 1] BARRIER B-write BARRIER B-read [pass 2]:
-    // two barriers instead of four, one rendezvous per frame.
-    //   * Pass-0 loads: a wave reads 16-byte pieces at 64-byte stride (its c bits), the four
-    //     waves of the workgroup cover the lines between them (L1 hits); stores keep 256-byte runs.
-    //   * Middle-pass twiddles W_{RA RB}^{b ka} depend on the lane (ka) only: deferred into the
-    //     butterflies (dft_regs_def) they are RB/2 register pairs per lane, resident for the
-    //     workgroup's lifetime; no twiddle is read from LDS per frame.
-    // LDS slots are 16 bytes (two complex, the c0 pair):
-    //   A (inside S_w): slot = 65 ka + 16 g + b      writer lane (b, g), reader lane (ka, g)
-    //   B:              slot = 17 m + j              m = ka + RA kb, j = c / 2; S_w = rows 64 w ..
-    // both conflict-free for ds_write_b128 (8 consecutive lanes -> 8 consecutive slots mod 8) and
-    // ds_read_b128 (a 16-lane group -> 16 distinct slots mod 16; 65 and 17 are odd).
-    // -----------------------------------------------------------------------------------------
-    static __device__ __forceinline__ void wave_order() {
-        // LDS operations of one wavefront execute in program order; this only stops the compiler
-        // from moving them across (and keeps the CPU emulation's lanes together)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    static __device__ __forceinline__ void run_v2(const FftArgs &a, cf *lds_all) {
-        constexpr int RA = Cfg::R(0), RB = Cfg::R(1), RC = Cfg::R(2);
-        static_assert(NP == 3 && FPW == 1 && (T % 64) == 0 && !ONE_WAVE, "V2 is for multi-wave frames in three passes");
-        static_assert(RA == 16 && RB == 16 && RC == 32 && P == 32, "V2 layout constants are written for 16 x 16 x 32");
-        static_assert(Cfg::TWR, "V2 keeps the last pass's twiddles in registers");
-        constexpr int G = 64 / RB;            // lane groups per wave (the c bits below the wave bits, above c0)
-        constexpr int ROW_B = RC / 2 + 1;     // 16-byte slots per B row (m), odd
-        constexpr int SW = 64 * ROW_B;        // slots of one wave's partition S_w
-        constexpr int ROW_A = 4 * RB + 1;     // slots between consecutive ka in the A layout, odd
-        static_assert((RA - 1) * ROW_A + 16 * (G - 1) + RB <= SW, "the A layout must fit the wave's partition");
-        static_assert(2 * SW * (T / 64) <= Cfg::LDS_FRAME, "LDS frame too small for the B layout");
-
-        const int tid = threadIdx.x;
-        const int w = tid >> 6, l = tid & 63;
-        unsigned *tk = reinterpret_cast<unsigned *>(lds_all + Cfg::LDS_TOTAL);
-        cf *lds = lds_all;
-
-        const unsigned bidx = blockIdx.x;
-        const bool issuer = (tid == 0);
-        const size_t n_units = a.n_frames;
-        Pools pools;
-        pools.n_units = (unsigned)n_units;
-        pools.grid = gridDim.x;
-        unsigned cur = bidx % POOLS;
-
-        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) {
-            const unsigned hw_id = read_hw_id(), xcc_id = read_xcc_id();
-            a.trace[32 * bidx + 0] = wall_clock64();
-            a.trace[32 * bidx + 2] = __builtin_readcyclecounter();
-            a.trace[32 * bidx + 4] = hw_id;
-            a.trace[32 * bidx + 5] = xcc_id;
-        }
-
-        const int mode = (MODE_T >= 0) ? MODE_T : a.mode;
-        const uint32_t xormask = (MODE_T >= 0) ? 0u : a.xormask;
-        const uint32_t esz = elem_bytes(mode);
-        const size_t total_in = (size_t)IN_BPS * ((a.n_frames - 1) * a.hop + (size_t)N);
-        const bool tiled = a.tile_rows != 0;
-        const size_t total_out = (size_t)esz * (tiled ? a.out_span : a.n_frames * (size_t)N);
-        auto row_elem = [&](size_t f) -> size_t {  // element offset of frame f's row (FPW == 1 here)
-            if (!tiled) return f * (size_t)N;
-            const uint32_t k = (uint32_t)f / a.tile_rows, y = (uint32_t)f - k * a.tile_rows;
-            return (size_t)y * a.pitch_row + (size_t)k * a.pitch_tile;
-        };
-        // pass 0: lane (b, g) of wave w holds samples n = a N/RA + b RC + (w G + g) C0 + c0
-        const int b0 = l % RB, g = l / RB;
-        const int n_base = b0 * RC + (w * G + g) * C0;
-        // ABL 16 (measurement only, wrong results): the V1 load mapping, 256-byte runs per wave
-        const uint32_t in_voff = (uint32_t)IN_BPS * (uint32_t)((Cfg::ABL & 16) ? C0 * tid : n_base);
-        // ABL 8 (measurement only): static unit interleave, next unit's bytes requested right after the
-        // conversion of this one's
-        constexpr bool STATIC = (Cfg::ABL & 8) != 0;
-        // pass 1: lane (ka, g); pass 2: thread m = ka + RA kb = tid
-        const int ka = l % RA;
-        const int m = tid;
-        const uint32_t out_elem = (uint32_t)m;
-
-        size_t u = (size_t)pools.start(cur) + bidx / POOLS;
-        if (u >= pools.start(cur + 1)) u = n_units;
-        if constexpr (STATIC) u = bidx;
-        unsigned tick_next = 0;
-
-        constexpr int TAB_COPY = Cfg::TAB_SMALL;
-        constexpr int TAB_REGS = (TAB_COPY + Cfg::WG - 1) / Cfg::WG;
-        cf tabv[TAB_REGS];
-#pragma unroll
-        for (int i = 0; i < TAB_REGS; ++i) {
-            const int e = tid + i * Cfg::WG;
-            tabv[i] = a.tw_small[e < TAB_COPY ? e : TAB_COPY - 1];
-        }
-        // this lane's deferred middle-pass twiddles: RB/2 pairs, resident
-        cf tw1[RB / 2];
-        ld_c<RB / 2>(a.tw_def + ka * (RB / 2), tw1);
-        Raw raw[R0];
-        load_raw(buffer_window(a.in, (size_t)IN_BPS * u * a.hop, u < n_units ? total_in : 0), in_voff, raw);
-        if (!STATIC && issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
-
-#pragma unroll
-        for (int i = 0; i < TAB_REGS; ++i) {
-            const int e = tid + i * Cfg::WG;
-            lds_all[Cfg::LDS_FRAME + (e < TAB_COPY ? e : TAB_COPY - 1)] = tabv[i];
-        }
-        __syncthreads();
-        cf twl[(RL - 1) * CL];
-        {
-            const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
-#pragma unroll
-            for (int r = 1; r < RL; ++r) {
-                const unsigned e = (unsigned)r * (unsigned)m;
-                cf tw = pk_cmul(hi[e >> 6], lo[e & 63u]);
-                if constexpr (PRESCALED) tw = tw * cf{SC, SC};
-                twl[r - 1] = tw;
-            }
-        }
-
-        cf ebase[ROT ? C0 : 1];
-        if constexpr (ROT) {
-#pragma unroll
-            for (int c = 0; c < C0; ++c) {
-                const unsigned n0 = (unsigned)(n_base + c);
-                const cf e = turn_phasor_f64(a.rot_delta * (double)n0);
-                ebase[c] = (n0 & 1u) ? -e : e;
-            }
-        }
-
-        unsigned par = 0;
-        if (!STATIC && u >= n_units) {
-            if (issuer) {
-                unsigned nu = pools.unit(cur, tick_next);
-                for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
-                    const unsigned q = (cur + k) % POOLS;
-                    nu = pools.unit(q, atomicAdd(a.ctr + 32 * q, 1u));
-                    if (nu != NO_UNIT) cur = q;
-                }
-                tk[0] = nu;
-                tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
-            }
-            __syncthreads();
-            const unsigned nu = __builtin_amdgcn_readfirstlane(tk[0]);
-            __syncthreads();
-            u = (nu == NO_UNIT) ? n_units : (size_t)nu;
-            load_raw(buffer_window(a.in, (size_t)IN_BPS * u * a.hop, u < n_units ? total_in : 0), in_voff, raw);
-        }
-
-        // LDS addresses (complex units; a slot is two complex)
-        cf *const sw = lds + 2 * SW * w;                                   // this wave's partition
-        cf *const a_wr = sw + 2 * (16 * g + b0);                           // + 2 ROW_A ka
-        const cf *const a_rd = sw + 2 * (ROW_A * ka + 16 * g);             // + 2 b
-        cf *const b_wr = lds + 2 * (ROW_B * ka + (w * G + g));             // + 2 ROW_B RA kb
-        const cf *const b_rd = lds + 2 * ROW_B * m;                        // + 2 j
-
-        unsigned iter = 0;
-        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) a.trace[32 * bidx + 6] = wall_clock64();
-        while (u < n_units) {
-            if (!STATIC && issuer) {
-                unsigned nu = pools.unit(cur, tick_next);
-                for (unsigned k = 1; nu == NO_UNIT && k < POOLS; ++k) {
-                    const unsigned q = (cur + k) % POOLS;
-                    nu = pools.unit(q, atomicAdd(a.ctr + 32 * q, 1u));
-                    if (nu != NO_UNIT) cur = q;
-                }
-                tk[par] = nu;
-                tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
-            }
-
-            cf v[P];
-            if constexpr (ROT) {
-                const size_t first = u * a.hop;
-                const cf ef = turn_phasor_f32(a.rot_phase0 + a.rot_delta * (double)first);
-                cf fr[C0];
-#pragma unroll
-                for (int c = 0; c < C0; ++c) fr[c] = pk_cmul(ebase[c], ef);
-#pragma unroll
-                for (int r = 0; r < R0; ++r) {
-                    convert_row<IN, C0, false>(raw[r], a.xormask, n_base, v + r * C0);
-                    const cf wr = a.rot_row[r];
-#pragma unroll
-                    for (int c = 0; c < C0; ++c) {
-                        v[r * C0 + c] = pk_cmul(v[r * C0 + c] + cf{128.0f, 128.0f}, pk_cmul_uniform(fr[c], wr));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < R0; ++r) convert_row<IN, C0>(raw[r], xormask, n_base, v + r * C0);
-            }
-            size_t un = u + gridDim.x;
-            if constexpr (STATIC) {
-                load_raw(buffer_window(a.in, (size_t)IN_BPS * un * a.hop, un < n_units ? total_in : 0), in_voff, raw);
-            }
-#pragma unroll
-            for (int c = 0; c < C0; ++c) dft_regs<R0, C0>(v + c);
-
-            // exchange A, inside this wave's partition: ka <-> b
-            if constexpr ((Cfg::ABL & 32) == 0) {  // ABL 32 (measurement only): no exchange A
-                wave_order();  // this wave's reads of the previous frame (B) precede these writes
-#pragma unroll
-                for (int r = 0; r < RA; ++r) st_c<2>(a_wr + 2 * ROW_A * r, v + 2 * r);
-                wave_order();
-#pragma unroll
-                for (int r = 0; r < RB; ++r) ld_c<2>(a_rd + 2 * r, v + 2 * r);
-                after_reads();
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) dft_regs_def<RB, 2, 1>(v + c, tw1);
-
-            __syncthreads();  // every wave has read its partition: the cross-wave writes may land
-            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * bidx + 7] = wall_clock64();
-            // exchange B, across waves: row m = ka + RA kb gets this lane's c pair at j = w G + g
-#pragma unroll
-            for (int r = 0; r < RB; ++r) st_c<2>(b_wr + 2 * ROW_B * RA * r, v + 2 * r);
-            __syncthreads();
-            // nothing but the writes sits between the two barriers; the ticket word is read in
-            // front of the data (LDS returns in order), and the next unit's bytes are requested
-            // while the rows come in
-            const unsigned tkv = STATIC ? 0u : tk[par];
-#pragma unroll
-            for (int j = 0; j < RC / 2; ++j) ld_c<2>(b_rd + 2 * j, v + 2 * j);
-            if constexpr (!STATIC) {
-                __builtin_amdgcn_sched_barrier(0);  // the reads are issued before the ticket is waited for
-                const unsigned nu = __builtin_amdgcn_readfirstlane(tkv);
-                par ^= 1u;
-                un = (nu == NO_UNIT) ? n_units : (size_t)nu;
-                load_raw(buffer_window(a.in, (size_t)IN_BPS * un * a.hop, un < n_units ? total_in : 0), in_voff, raw);
-            }
-            after_reads();
-
-            if constexpr (TW_FUSE) {
-                dft_regs_tw<RL, 1, 1>(v, twl, PRESCALED ? SC : 1.0f);
-            } else {
-                if constexpr (PRESCALED) v[0] = v[0] * cf{SC, SC};
-#pragma unroll
-                for (int r = 1; r < RL; ++r) v[r] = pk_cmul(v[r], twl[r - 1]);
-                dft_regs<RL, 1>(v);
-            }
-            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(u), total_out), out_elem, v, m);
-            u = un;
-            if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter < 24) a.trace[32 * bidx + 8 + iter] = wall_clock64();
-            ++iter;
-        }
-
-        if (!STATIC && issuer) {
-            __builtin_amdgcn_s_waitcnt(0);
-            const unsigned finished = atomicAdd(a.ctr + 32 * POOLS, 1u);
-            if (finished == gridDim.x - 1) {
-#pragma unroll
-                for (unsigned q = 0; q <= POOLS; ++q) a.ctr[32 * q] = 0;
-            }
-        }
-        if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0) {
-            a.trace[32 * bidx + 1] = wall_clock64();
-            a.trace[32 * bidx + 3] = __builtin_readcyclecounter();
-        }
-    }
 
     static __device__ __forceinline__ void run_v1(const FftArgs &a, cf *lds_all) {
-        // OPT 1024: static priority for the second resident workgroup of every CU (blocks are placed
-        // round-robin, so block b and b + grid/2 share a CU): one of the two co-resident waves of a
-        // SIMD always wins the VALU, the other fills its gaps
-        if constexpr ((Cfg::OPT & 1024) != 0) {
-            if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(1);
-        }
         const int tid = threadIdx.x;
         const int slot = (FPW == 1) ? 0 : tid / T;  // frame index inside the unit = LDS region
         const int t = (FPW == 1) ? tid : tid % T;
@@ -1773,13 +1190,12 @@ struct FftKernel {
         // pipe of a CU busy for 1.5 us in front of the first frame (scripts/wg_trace.py: tables in LDS at 1.6 us, twiddles
         // built at 3.1 us).  Instead r = RB a + b: W^{r k} = W^{RB a k} * W^{b k}, so only RL/RB - 1 + RB - 1 values are
         // gathered (10 instead of 31 at RL = 32) and the rest are products of two of those -- the same number of complex
-        // multiplies, one rounding more on the composite ones.  OPT 524288 (tuning): the direct form.
-        constexpr bool TWL_DIRECT = (Cfg::OPT & 524288) != 0;
+        // multiplies, one rounding more on the composite ones.
         cf twl[Cfg::TWR ? (RL - 1) * CL : 1];
         if constexpr (Cfg::TWR) {
             const cf *hi = lds_all + Cfg::LDS_HI, *lo = lds_all + Cfg::LDS_LO;
             auto root = [&](unsigned m) -> cf { return pk_cmul(hi[m >> 6], lo[m & 63u]); };  // W^m, m < N * RL
-            constexpr int RB = TWL_DIRECT ? RL : (RL >= 16 ? 8 : (RL >= 4 ? 2 : RL));  // low digit of r
+            constexpr int RB = RL >= 16 ? 8 : (RL >= 4 ? 2 : RL);  // low digit of r
             constexpr int RA = RL / RB;
 #pragma unroll
             for (int c = 0; c < CL; ++c) {
@@ -1850,17 +1266,6 @@ struct FftKernel {
                 tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
             }
 
-            // OPT 262144 (tuning): the two workgroups of a CU (blocks b and b + grid / 2) tell each other how many frames they
-            // have done; the one behind raises its issue priority, the one ahead lowers it
-            [[maybe_unused]] unsigned partner_progress = 0;
-            if constexpr ((Cfg::OPT & 262144) != 0) {
-                unsigned *prog = a.ctr + 9 * 32;
-                const unsigned half = gridDim.x >> 1;
-                const unsigned partner = b < half ? b + half : b - half;
-                if (tid == 0) __hip_atomic_store(prog + b, iter + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                partner_progress = __hip_atomic_load(prog + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-
             // A lane without a frame (ragged last unit) still runs the barriers; it simply
             // transforms the zeros its loads returned and its stores are dropped.
             cf v[P];
@@ -1898,9 +1303,8 @@ struct FftKernel {
                 pass0_windowed(v, wv);
             } else {
 #pragma unroll
-                for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & 4) != 0, MI>(v + c);
+                for (int c = 0; c < C0; ++c) dft_regs<R0, C0, (Cfg::ABL & abl::NO_FLOPS) != 0>(v + c);
             }
-            if constexpr (LAZY_SYNC) lazy_sync();  // the previous frame's last read is complete everywhere
             lds_write<0>(lds, v, t);
             frame_sync();
             if ((FSEA_TRACE != 0) && a.trace != nullptr && tid == 0 && iter == 0) a.trace[32 * b + 7] = wall_clock64();  // first pass 0 done
@@ -1910,82 +1314,37 @@ struct FftKernel {
             [[maybe_unused]] size_t fnext = 0;
             [[maybe_unused]] bool same_run = false;
             if constexpr (RUNS) {
-                static_assert(!RUNS || !TK_LATE, "half-overlap runs use the plain prefetch");
                 same_run = (jpos + 1 < a.run_len) && (fcur + 1 < a.n_frames);
                 un = same_run ? u : u + gridDim.x;
                 fnext = same_run ? fcur + 1 : un * (size_t)a.run_len;
             }
-            if constexpr (TK_LATE) {
-                // the ticket word is read in front of pass 1's data (LDS returns in order) and only
-                // waited for once those reads are in flight
-                const unsigned tkv = tk[par];
-                middle_pass<1>(lds, lds_all, v, a, t, tw1, [&]() {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (dyn) {
-                        const unsigned nu = __builtin_amdgcn_readfirstlane(tkv);
-                        par ^= 1u;
-                        un = (nu == NO_UNIT) ? n_units : (size_t)nu;
-                    }
-                    load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff,
-                             raw);
-                });
-            } else {
-                if constexpr ((Cfg::OPT & 65536) != 0) {
-                    if ((iter + (blockIdx.x >= gridDim.x / 2 ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(2);
-                    else __builtin_amdgcn_s_setprio(0);
-                }
-                if constexpr ((Cfg::OPT & 262144) != 0) {
-                    const unsigned pp = __builtin_amdgcn_readfirstlane(partner_progress);
-                    if (pp > iter + 1u) __builtin_amdgcn_s_setprio(3);
-                    else if (pp < iter + 1u) __builtin_amdgcn_s_setprio(0);
-                    else __builtin_amdgcn_s_setprio(1);
-                }
-                if (dyn) {
-                    if constexpr (Cfg::ABL & 2) __syncthreads();  // the ablation removed the barrier that publishes tk
-                    const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
-                    par ^= 1u;
-                    un = (nu == NO_UNIT) ? n_units : (size_t)nu;
-                    // OPT 65536 (tuning): the two workgroups of a CU take turns at the higher issue priority, frame by frame;
-                    // OPT 131072 (tuning): a workgroup that has had fewer units than its pool's average so far raises its
-                    // priority, one that is ahead lowers it (the unit number says how many the pool has handed out)
-                    if constexpr ((Cfg::OPT & 131072) != 0) {
-                        if (nu != NO_UNIT) {
-                            const unsigned q = (unsigned)(((size_t)nu * POOLS) / pools.n_units);  // pool the unit came from
-                            const unsigned handed = nu - pools.start(q < POOLS ? q : POOLS - 1);
-                            const unsigned mine = (iter + 2u) * pools.homed(b % POOLS);         // units this workgroup has had, scaled
-                            if (mine < handed) __builtin_amdgcn_s_setprio(3);
-                            else __builtin_amdgcn_s_setprio(0);
-                        }
-                    }
-                }
-                if constexpr (RUNS) {
-                    const rsrc_t rs = buffer_window(a.in, (size_t)IN_BPS * fnext * a.hop, un < n_units ? total_in : 0);
-                    if (same_run) {  // the bytes of rows R0/2 .. R0-1 are rows 0 .. R0/2-1 of the next frame: only its second half is fetched
-#pragma unroll
-                        for (int r = 0; r < R0 / 2; ++r) raw[r] = raw[r + R0 / 2];
-                        load_raw_rows<R0 / 2, R0>(rs, in_voff, raw);
-                    } else {
-                        load_raw(rs, in_voff, raw);
-                    }
-                } else if constexpr ((Cfg::ABL & 64) == 0) {  // ABL 64 (measurement only): the first unit's bytes are reused
-                    load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
-                }
-                middle_pass<1>(lds, lds_all, v, a, t, tw1);
+            if (dyn) {
+                if constexpr (Cfg::ABL & abl::NO_LDS) __syncthreads();  // the ablation removed the barrier that publishes tk
+                const unsigned nu = __builtin_amdgcn_readfirstlane(tk[par]);
+                par ^= 1u;
+                un = (nu == NO_UNIT) ? n_units : (size_t)nu;
             }
+            if constexpr (RUNS) {
+                const rsrc_t rs = buffer_window(a.in, (size_t)IN_BPS * fnext * a.hop, un < n_units ? total_in : 0);
+                if (same_run) {  // the bytes of rows R0/2 .. R0-1 are rows 0 .. R0/2-1 of the next frame: only its second half is fetched
+#pragma unroll
+                    for (int r = 0; r < R0 / 2; ++r) raw[r] = raw[r + R0 / 2];
+                    load_raw_rows<R0 / 2, R0>(rs, in_voff, raw);
+                } else {
+                    load_raw(rs, in_voff, raw);
+                }
+            } else if constexpr ((Cfg::ABL & abl::NO_LOADS) == 0) {  // (measurement only: the first unit's bytes are reused)
+                load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
+            }
+            middle_pass<1>(lds, lds_all, v, a, t, tw1);
 
             // last pass
             lds_read<LAST>(lds, v, tl);
             after_reads();
-            if constexpr (!LAZY_SYNC) frame_sync();  // the buffer is free for the next frame's pass 0
-            [[maybe_unused]] cf pp[PW ? (RL / 2) * CL : 1];
-            if constexpr (PW) {
-                const float dc_hi = PW_DC ? dc_restore(mode, tl) : 0.0f;
-                dft_regs_tw_pw<RL, CL, CL, MI, PW_DC>(v, twl, PRESCALED ? SC : 1.0f, pp, dc_hi);
+            frame_sync();  // the buffer is free for the next frame's pass 0
+            if constexpr (Cfg::TWR && TW_FUSE) {
 #pragma unroll
-                for (int c = 1; c < CL; ++c) dft_regs_tw_pw<RL, CL, CL, MI, false>(v + c, twl + c, PRESCALED ? SC : 1.0f, pp + c);
-            } else if constexpr (Cfg::TWR && TW_FUSE) {
-#pragma unroll
-                for (int c = 0; c < CL; ++c) dft_regs_tw<RL, CL, CL, MI>(v + c, twl + c, PRESCALED ? SC : 1.0f);
+                for (int c = 0; c < CL; ++c) dft_regs_tw<RL, CL, CL>(v + c, twl + c, PRESCALED ? SC : 1.0f);
             } else if constexpr (Cfg::TWR) {
                 if constexpr (PRESCALED) {
 #pragma unroll
@@ -1995,7 +1354,7 @@ struct FftKernel {
                 for (int r = 1; r < RL; ++r) {
 #pragma unroll
                     for (int c = 0; c < CL; ++c) {
-                        if constexpr (Cfg::ABL & 4) v[r * CL + c] += twl[(r - 1) * CL + c];
+                        if constexpr (Cfg::ABL & abl::NO_FLOPS) v[r * CL + c] += twl[(r - 1) * CL + c];
                         else v[r * CL + c] = pk_cmul(v[r * CL + c], twl[(r - 1) * CL + c]);
                     }
                 }
@@ -2004,7 +1363,7 @@ struct FftKernel {
             }
             if constexpr (!(Cfg::TWR && TW_FUSE)) {
 #pragma unroll
-                for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & 4) != 0, MI>(v + c);
+                for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & abl::NO_FLOPS) != 0>(v + c);
             }
             if constexpr (WIN != 0) {
                 // the offset-binary DC term's spectrum, for this lane's bins of the two rows around N/2
@@ -2028,7 +1387,7 @@ struct FftKernel {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(RUNS ? fcur : u * FPW), total_out), out_elem, v, tl, pp);
+            epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(RUNS ? fcur : u * FPW), total_out), out_elem, v, tl);
             u = un;
             if constexpr (RUNS) {
                 fcur = fnext;
@@ -2038,9 +1397,6 @@ struct FftKernel {
             ++iter;
         }
 
-        if constexpr ((Cfg::OPT & 262144) != 0) {
-            if (tid == 0) __hip_atomic_store(a.ctr + 9 * 32 + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch
-        }
         // this worker is done: its outstanding ticket request must have landed before it is
         // counted, so that the last worker's reset cannot be overtaken by a late increment
         if (dyn && issuer) {

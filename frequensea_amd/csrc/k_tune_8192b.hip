@@ -2,28 +2,16 @@
 #include "fsea_configs_tune.h"
 #include "fsea_registry.h"
 FSEA_DEFINE_KERNEL_LITE(fsea_fft8192x0, "x0", FSEA_CFG_8192_X0)
-FSEA_DEFINE_KERNEL_LITE(fsea_fft8192x7, "x7", FSEA_CFG_8192_X7)
-FSEA_DEFINE_KERNEL_LITE(fsea_fft8192tk, "tk", FSEA_CFG_8192_TK)
-FSEA_DEFINE_KERNEL_LITE(fsea_fft8192pr, "pr", FSEA_CFG_8192_PR)
 FSEA_DEFINE_KERNEL_LITE(fsea_fft8192v2, "v2", FSEA_CFG_8192_V2)
 FSEA_DEFINE_KERNEL_LITE(fsea_fft8192v2s, "v2s", FSEA_CFG_8192_V2S)
 FSEA_DEFINE_KERNEL_LITE(fsea_fft8192stnt, "st_nt", FSEA_CFG_8192_STNT)
-FSEA_DEFINE_KERNEL_LITE(fsea_fft8192stsc1, "st_sc1", FSEA_CFG_8192_STSC1)
-FSEA_DEFINE_KERNEL_LITE(fsea_fft8192stsc01, "st_sc0sc1", FSEA_CFG_8192_STSC01)
-FSEA_DEFINE_KERNEL_LITE(fsea_fft8192stsc1nt, "st_sc1nt", FSEA_CFG_8192_STSC1NT)
 FSEA_DEFINE_KERNEL_LITE(fsea_fft8192ldnt, "ld_nt", FSEA_CFG_8192_LDNT)
 FSEA_DEFINE_KERNEL_LITE(fsea_fft8192cp0, "cp0", FSEA_CFG_8192_CP0)
 FSEA_REGISTER_BEGIN(tune_8192b)
 FSEA_REGISTER(fsea_fft8192x0)
-FSEA_REGISTER(fsea_fft8192x7)
-FSEA_REGISTER(fsea_fft8192tk)
-FSEA_REGISTER(fsea_fft8192pr)
 FSEA_REGISTER(fsea_fft8192v2)
 FSEA_REGISTER(fsea_fft8192v2s)
 FSEA_REGISTER(fsea_fft8192stnt)
-FSEA_REGISTER(fsea_fft8192stsc1)
-FSEA_REGISTER(fsea_fft8192stsc01)
-FSEA_REGISTER(fsea_fft8192stsc1nt)
 FSEA_REGISTER(fsea_fft8192ldnt)
 FSEA_REGISTER(fsea_fft8192cp0)
 FSEA_REGISTER_END

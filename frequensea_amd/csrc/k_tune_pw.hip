@@ -2,32 +2,16 @@
 // 32 / 64 points with two lanes per frame.
 #include "fsea_configs_tune.h"
 #include "fsea_registry.h"
-FSEA_DEFINE_KERNEL_U8(fsea_fft8192pw, "pw", FSEA_CFG_8192_PW)
-FSEA_DEFINE_KERNEL_U8(fsea_fft16384pw, "pw", FSEA_CFG_16384_PW)
-FSEA_DEFINE_KERNEL_U8(fsea_fft4096pw, "pw", FSEA_CFG_4096_PW)
-FSEA_DEFINE_KERNEL_U8(fsea_fft2048pw, "pw", FSEA_CFG_2048_PW)
-FSEA_DEFINE_KERNEL_U8(fsea_fft1024pw, "pw", FSEA_CFG_1024_PW)
 FSEA_DEFINE_KERNEL_U8(fsea_fft512f8, "f8", FSEA_CFG_512_F8)
-FSEA_DEFINE_KERNEL_U8(fsea_fft512pw, "pw", FSEA_CFG_512_PW)
 FSEA_DEFINE_KERNEL_U8(fsea_fft256f8, "f8", FSEA_CFG_256_F8)
-FSEA_DEFINE_KERNEL_U8(fsea_fft256pw, "pw", FSEA_CFG_256_PW)
-FSEA_DEFINE_KERNEL_U8(fsea_fft128pw, "pw", FSEA_CFG_128_PW)
 FSEA_DEFINE_KERNEL_U8(fsea_fft32t2a, "t2a", FSEA_CFG_32_T2A)
 FSEA_DEFINE_KERNEL_U8(fsea_fft32t2b, "t2b", FSEA_CFG_32_T2B)
 FSEA_DEFINE_KERNEL_U8(fsea_fft32t2c, "t2c", FSEA_CFG_32_T2C)
 FSEA_DEFINE_KERNEL_U8(fsea_fft64t2c, "t2c", FSEA_CFG_64_T2C)
 FSEA_DEFINE_KERNEL_U8(fsea_fft64t2d, "t2d", FSEA_CFG_64_T2D)
 FSEA_REGISTER_BEGIN(tune_pw)
-FSEA_REGISTER(fsea_fft8192pw)
-FSEA_REGISTER(fsea_fft16384pw)
-FSEA_REGISTER(fsea_fft4096pw)
-FSEA_REGISTER(fsea_fft2048pw)
-FSEA_REGISTER(fsea_fft1024pw)
 FSEA_REGISTER(fsea_fft512f8)
-FSEA_REGISTER(fsea_fft512pw)
 FSEA_REGISTER(fsea_fft256f8)
-FSEA_REGISTER(fsea_fft256pw)
-FSEA_REGISTER(fsea_fft128pw)
 FSEA_REGISTER(fsea_fft32t2a)
 FSEA_REGISTER(fsea_fft32t2b)
 FSEA_REGISTER(fsea_fft32t2c)

@@ -16,7 +16,7 @@ TOTAL = 1 << 27
 MODE = int(os.environ.get("ENERGY_MODE", "0"))          # epilogue mode (0 = MAG_F32, 1 = DB10_U8, 2 = DB5_U8_DCFIX, ...)
 OUT_BYTES = {0: 4, 1: 1, 2: 1, 3: 8, 4: 4, 5: 4}[MODE]
 SECONDS = float(os.environ.get("ENERGY_SECONDS", "4"))
-variants = sys.argv[1:] or ["-", "r1", "nd", "abl_io", "abl_nolds", "abl_noflop"]
+variants = sys.argv[1:] or ["-", "nd", "abl_io", "abl_nolds", "abl_noflop"]
 L = fsea.hip_lib()
 host = np.random.default_rng(1).integers(-70, 70, 2 * TOTAL, dtype=np.int8).view(np.uint8)
 if os.environ.get("ENERGY_CONST_INPUT"):

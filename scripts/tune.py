@@ -14,16 +14,14 @@ from frequensea_amd import fsea  # noqa: E402
 fsea.use_tune_library()
 
 VARIANTS = {
-    8192: ["", "cp0", "r1", "nd", "st_nt", "st_sc1", "st_sc0sc1", "st_sc1nt", "ld_nt", "x0", "x7", "tk", "pr", "v2", "v2s",
-           "A", "B", "D", "B2", "D2", "W", "W2", "static", "palt", "pcatch", "notwl", "notwr",
+    8192: ["", "cp0", "nd", "st_nt", "ld_nt", "x0", "v2", "v2s", "A", "B", "D", "B2", "D2", "W", "W2", "notwl", "notwr",
            "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu", "abl_noload", "abl_nomag",
-           "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na",
-           "abl_io_nt_ws", "abl_io_nt_wl", "abl_io_nt_wls", "abl_ws", "abl_wl", "abl_wls", "abl_px_nolog", "abl_px_wide"],
-    1024: ["", "cp0", "ldst_nt", "r1", "x0", "B", "C", "D"],
-    4096: ["", "w64", "s2", "nr", "cp0", "st_nt", "r1", "t256", "x0", "df", "B", "B3", "C", "D",
-           "abl_px_nolog", "abl_px_nost", "abl_px_wide", "abl_px_io", "abl_px_io_wide"],
+           "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na", "abl_px_nolog"],
+    1024: ["", "cp0", "ldst_nt", "x0", "B", "C", "D"],
+    4096: ["", "w64", "s2", "nr", "cp0", "st_nt", "t256", "x0", "df", "B", "B3", "C", "D",
+           "abl_px_nolog", "abl_px_nost", "abl_px_io"],
     32: [""], 64: [""], 128: ["", "p16"], 256: ["", "cp0", "ldst_nt", "p16"], 512: [""], 2048: ["", "nr", "cp0", "st_nt", "x0", "df", "B", "C"],
-    16384: ["", "cp0", "st_nt", "r1", "nd", "B"],
+    16384: ["", "cp0", "st_nt", "nd", "B"],
 }
 TOTAL_SAMPLES = 1 << 27          # 256 MiB in + 512 MiB out per launch
 ROUNDS = 7

@@ -16,11 +16,8 @@ int emu_variants_a(int n, const std::string &v, int in_kind, int mt, const fsea:
         EMU_VARIANT(8192, "B2", FSEA_CFG_8192_B2)
         EMU_VARIANT(8192, "D2", FSEA_CFG_8192_D2)
         EMU_VARIANT(8192, "W", FSEA_CFG_8192_W)
-        EMU_VARIANT(8192, "static", FSEA_CFG_8192_STATIC)
         EMU_VARIANT(4096, "nr", FSEA_CFG_4096_LR)
         EMU_VARIANT(2048, "nr", FSEA_CFG_2048_LR)
-        EMU_VARIANT(8192, "twe", FSEA_CFG_8192_TWE)
-        EMU_VARIANT(4096, "twe", FSEA_CFG_4096_TWE)
     EMU_VARIANT(1024, "r2", FSEA_CFG_1024_R2)
     EMU_VARIANT(1024, "e", FSEA_CFG_1024_E)
     EMU_VARIANT(1024, "h", FSEA_CFG_1024_H)

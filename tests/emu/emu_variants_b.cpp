@@ -2,15 +2,10 @@
 #include "emu_common.h"
 
 int emu_variants_b(int n, const std::string &v, int in_kind, int mt, const fsea::FftArgs &a, unsigned grid) {
-        EMU_VARIANT(1024, "twe", FSEA_CFG_1024_TWE)
-        EMU_VARIANT(8192, "r1", FSEA_CFG_8192_R1)
         EMU_VARIANT(8192, "nd", FSEA_CFG_8192_ND)
         EMU_VARIANT(8192, "v2", FSEA_CFG_8192_V2)
         EMU_VARIANT(8192, "v2s", FSEA_CFG_8192_V2S)
-        EMU_VARIANT(8192, "tk", FSEA_CFG_8192_TK)
-        EMU_VARIANT(8192, "pr", FSEA_CFG_8192_PR)
         EMU_VARIANT(8192, "x0", FSEA_CFG_8192_X0)
-        EMU_VARIANT(8192, "x7", FSEA_CFG_8192_X7)
         EMU_VARIANT(8192, "A", FSEA_CFG_8192_A)
         EMU_VARIANT(8192, "B", FSEA_CFG_8192_B)
         EMU_VARIANT(8192, "D", FSEA_CFG_8192_D)

@@ -3,7 +3,6 @@
 
 int emu_variants_c(int n, const std::string &v, int in_kind, int mt, const fsea::FftArgs &a, unsigned grid) {
         EMU_VARIANT(4096, "f1", FSEA_CFG_4096_F1)
-        EMU_VARIANT(4096, "r1", FSEA_CFG_4096_R1)
         EMU_VARIANT(4096, "t256", FSEA_CFG_4096_T256)
         EMU_VARIANT(4096, "B3", FSEA_CFG_4096_B3)
         EMU_VARIANT(4096, "C", FSEA_CFG_4096_C)
@@ -12,23 +11,13 @@ int emu_variants_c(int n, const std::string &v, int in_kind, int mt, const fsea:
         EMU_VARIANT(2048, "df", FSEA_CFG_2048_DF)
         EMU_VARIANT(2048, "B", FSEA_CFG_2048_B)
         EMU_VARIANT(2048, "C", FSEA_CFG_2048_C)
-        EMU_VARIANT(1024, "r1", FSEA_CFG_1024_R1)
         EMU_VARIANT(1024, "x0", FSEA_CFG_1024_X0)
         EMU_VARIANT(1024, "B", FSEA_CFG_1024_B)
         EMU_VARIANT(1024, "C", FSEA_CFG_1024_C)
         EMU_VARIANT(1024, "D", FSEA_CFG_1024_D)
-        EMU_VARIANT(16384, "r1", FSEA_CFG_16384_R1)
         EMU_VARIANT(16384, "nd", FSEA_CFG_16384_ND)
         EMU_VARIANT(16384, "B", FSEA_CFG_16384_B)
-        EMU_VARIANT(8192, "pw", FSEA_CFG_8192_PW)
-        EMU_VARIANT(16384, "pw", FSEA_CFG_16384_PW)
-        EMU_VARIANT(4096, "pw", FSEA_CFG_4096_PW)
-        EMU_VARIANT(2048, "pw", FSEA_CFG_2048_PW)
-        EMU_VARIANT(1024, "pw", FSEA_CFG_1024_PW)
-        EMU_VARIANT(512, "pw", FSEA_CFG_512_PW)
         EMU_VARIANT(512, "f8", FSEA_CFG_512_F8)
-        EMU_VARIANT(256, "pw", FSEA_CFG_256_PW)
         EMU_VARIANT(256, "f8", FSEA_CFG_256_F8)
-        EMU_VARIANT(128, "pw", FSEA_CFG_128_PW)
     return -2;
 }

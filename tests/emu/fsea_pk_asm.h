@@ -36,44 +36,11 @@ static inline cf pk_cmul_add_mi(cf a, cf w, cf c) {
     return t;
 }
 
-// the last butterfly level in power form (planar results of a butterfly pair)
-static inline cf pk_pm_re(cf a, cf b) { return cf{a[0] + b[0], a[0] - b[0]}; }
-static inline cf pk_pm_im(cf a, cf b) { return cf{a[1] + b[1], a[1] - b[1]}; }
-static inline cf pk_pm_re_mi(cf a, cf b) { return cf{a[0] + b[1], a[0] - b[1]}; }
-static inline cf pk_pm_im_mi(cf a, cf b) { return cf{a[1] - b[0], a[1] + b[0]}; }
-static inline cf pk_pm_re_w(cf a, cf b, cf w) {
-    cf t = cf{fmaf(b[0], w[0], a[0]), fmaf(b[0], -w[0], a[0])};
-    return cf{fmaf(b[1], -w[1], t[0]), fmaf(b[1], w[1], t[1])};
-}
-static inline cf pk_pm_im_w(cf a, cf b, cf w) {
-    cf t = cf{fmaf(b[1], w[0], a[1]), fmaf(b[1], -w[0], a[1])};
-    return cf{fmaf(b[0], w[1], t[0]), fmaf(b[0], -w[1], t[1])};
-}
-
-
-// cross-lane primitives of the single-wave 64 x 64 schedule: every lane of the emulated wavefront publishes its
-// value, then reads the lane it needs (emu_main.cpp)
-unsigned emu_lane_read(unsigned v, int src_lane);  // src_lane: lane index inside this work-item's wavefront
-static inline void lane_swap32(uint32_t &a, uint32_t &b) {
-    const int lane = (int)(threadIdx.x & 63);
-    const uint32_t pa = emu_lane_read(a, lane ^ 32), pb = emu_lane_read(b, lane ^ 32);
-    if (lane >= 32) a = pb;   // a[32..63] <- b[0..31]
-    else b = pa;              // b[0..31]  <- a[32..63]
-}
-static inline uint32_t quad_xor1(uint32_t v) { return emu_lane_read(v, (int)((threadIdx.x & 63) ^ 1)); }
-static inline uint32_t quad_xor2(uint32_t v) { return emu_lane_read(v, (int)((threadIdx.x & 63) ^ 2)); }
-static inline uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
-    const uint64_t both = ((uint64_t)hi << 32) | lo;
-    uint32_t r = 0;
-    for (int i = 0; i < 4; ++i) r |= (uint32_t)((both >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
-    return r;
-}
 static inline uint32_t cvt_pk_u8(float f, uint32_t pos, uint32_t old) {
     const float c = f < 0.0f ? 0.0f : (f > 255.0f ? 255.0f : f);  // (NaN does not occur: p >= 0)
     const uint32_t u = (uint32_t)nearbyintf(c);                   // round to nearest even, as the instruction
     return (old & ~(0xffu << (8 * pos))) | (u << (8 * pos));
 }
-static inline uint32_t read_lane(uint32_t v, int lane) { return emu_lane_read(v, lane); }
 static inline float trunc_f32(float x) { return truncf(x); }
 
 static inline unsigned read_hw_id() { return 0; }

@@ -21,8 +21,9 @@ def emu_lib():
         out = os.path.join(emu, "libfsea_emu.so")
         csrc = os.path.join(ROOT, "frequensea_amd", "csrc")
         deps = srcs + [os.path.join(emu, "emu_common.h"), os.path.join(emu, "hip", "hip_runtime.h")] + [
-            os.path.join(csrc, f) for f in ("fsea_fft_core.h", "fsea_configs.h", "fsea_configs_tune.h", "fsea_tables.h")] + [
-            os.path.join(emu, "fsea_pk_asm.h")]
+            os.path.join(csrc, f) for f in ("fsea_fft_core.h", "fsea_fft_tune_members.h", "fsea_opt.h", "fsea_configs.h",
+                                             "fsea_configs_tune.h", "fsea_tables.h")] + [
+            os.path.join(emu, "fsea_pk_asm.h"), os.path.join(emu, "fsea_pk_asm_tune.h")]
         def stale():
             return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
@@ -32,7 +33,7 @@ def emu_lib():
                 fcntl.flock(lock, fcntl.LOCK_EX)
                 if stale():
                     from concurrent.futures import ThreadPoolExecutor
-                    flags = ["g++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-Wno-unknown-pragmas", "-I" + emu, "-I" + csrc]
+                    flags = ["g++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-Wno-unknown-pragmas", "-DFSEA_TUNE", "-I" + emu, "-I" + csrc]
                     objs = ["%s.%d.o" % (s_[:-4], os.getpid()) for s_ in srcs]
 
                     def compile_one(pair):

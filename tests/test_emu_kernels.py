@@ -113,12 +113,12 @@ def test_edge_inputs():
     assert emu_rows(z, n, 0).shape == (0, n)
 
 
-@pytest.mark.parametrize("n,variant", [(8192, "r1"), (8192, "nd"), (8192, "v2"), (8192, "v2s"), (8192, "tk"), (8192, "pr"),
-                                       (8192, "x0"), (8192, "x7"), (8192, "A"), (8192, "B"), (8192, "D"), (8192, "B2"), (8192, "D2"), (8192, "W"), (8192, "static"),
-                                       (8192, "notwl"), (8192, "notwr"), (4096, "nr"), (2048, "nr"), (8192, "twe"), (4096, "twe"), (1024, "twe"), (4096, "x0"), (4096, "df"), (4096, "r1"), (4096, "t256"), (4096, "B3"), (4096, "B"),
+@pytest.mark.parametrize("n,variant", [(8192, "nd"), (8192, "v2"), (8192, "v2s"),
+                                       (8192, "x0"), (8192, "A"), (8192, "B"), (8192, "D"), (8192, "B2"), (8192, "D2"), (8192, "W"),
+                                       (8192, "notwl"), (8192, "notwr"), (4096, "nr"), (2048, "nr"), (4096, "x0"), (4096, "df"), (4096, "t256"), (4096, "B3"), (4096, "B"),
                                        (4096, "C"), (4096, "D"), (2048, "x0"), (2048, "df"), (2048, "B"), (2048, "C"),
-                                       (1024, "r1"), (1024, "x0"), (1024, "B"), (1024, "C"), (1024, "D"),
-                                       (16384, "r1"), (16384, "nd"), (16384, "B"), (256, "p16"), (128, "p16"),
+                                       (1024, "x0"), (1024, "B"), (1024, "C"), (1024, "D"),
+                                       (16384, "nd"), (16384, "B"), (256, "p16"), (128, "p16"),
                                        (4096, "w64"), (4096, "w64b"), (4096, "s2"), (4096, "pk"), (4096, "px0"), (8192, "pk"), (8192, "px0"),
                                        (256, "pk"), (256, "px0"), (1024, "px0"), (256, "p64"), (1024, "r2"), (1024, "e"), (1024, "h")])
 def test_tuning_variants(n, variant):
@@ -128,31 +128,6 @@ def test_tuning_variants(n, variant):
     for mode in (0, 1, 3):
         got = emu_rows(iq, n, nf, mode=mode, grid=2, specialised=(mode == 0), variant=variant)
         parity.check_mode(got, iq, n, nf, n, True, mode)
-
-
-@pytest.mark.parametrize("n,variant", [(8192, "pw"), (16384, "pw"), (4096, "pw"), (2048, "pw"), (1024, "pw"), (512, "pw"), (512, "f8"),
-                                       (256, "pw"), (256, "f8"), (128, "pw")])
-def test_last_level_in_power_form(n, variant):
-    """OPT 8388608: the compile-time MAG / DB10 / DB5 kernels form |X|^2 of the last level's butterfly pairs planar
-    (fsea::dft_power_level) instead of two complex outputs each.  Every mode that uses it, both byte conventions' DC
-    handling (DB10 keeps bin N/2: the restored offset-binary DC term goes into the power form), overlapped frames."""
-    nf = 9 if n <= 1024 else 3
-    iq = synth_iq(n + 77, 2 * nf * n)
-    for mode in (0, 1, 2):
-        got = emu_rows(iq, n, nf, mode=mode, grid=2, specialised=True, variant=variant)
-        parity.check_mode(got, iq, n, nf, n, True, mode)
-    # near-constant offset-binary input: bin N/2 carries 0.5 N (1 + i), which DB10 pixels keep (255 there) and the
-    # patched modes overwrite with their left neighbour
-    quiet = (np.random.default_rng(n).integers(-2, 3, 2 * nf * n) + 128).astype(np.uint8) ^ np.uint8(0x80)
-    for mode in (1, 2, 0):
-        got = emu_rows(quiet, n, nf, mode=mode, grid=2, specialised=True, variant=variant)
-        parity.check_mode(got, quiet, n, nf, n, True, mode)
-        if mode == 1:
-            assert (got[:, n // 2] == 255).all() and (got[:, n // 2 - 1] < 200).all()
-    hop = n // 2
-    iq2 = synth_iq(n + 78, 2 * ((nf - 1) * hop + n))
-    got = emu_rows(iq2, n, nf, hop=hop, mode=2, grid=2, specialised=True, variant=variant)
-    parity.check_mode(got, iq2, n, nf, hop, True, 2)
 
 
 def test_random_geometry_sweep():
