@@ -655,10 +655,14 @@ def test_full_size_properties(n, nf):
     for f in rows:
         want = O.rows(iq[2 * f * n: 2 * (f + 1) * n], 1, n)[0]
         parity.check_float(got[f], want)
-    # MAG == MAG_NODC everywhere except the patched bin
+    # MAG == MAG_NODC everywhere except the patched bin: bit for bit where the two modes run the same configuration of the
+    # size, within the rounding of two radix orders where they do not (1024 points: frequensea_amd/csrc/fsea_configs.h)
     keep = np.ones(n, bool)
     keep[n // 2] = False
-    assert np.array_equal(got[:, keep], mag[:, keep].astype(np.float32))
+    if kernel_stem(n, fsea.MODE_MAG_F32) == kernel_stem(n, fsea.MODE_MAG_NODC_F32):
+        assert np.array_equal(got[:, keep], mag[:, keep].astype(np.float32))
+    else:
+        assert np.max(np.abs(got[:, keep] - mag[:, keep])) <= 2e-6 * mag.max()
     d_in.free()
     d_out.free()
     plan.close()
