@@ -224,29 +224,51 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     px = torch.empty((hi - lo, rows, n), dtype=torch.uint8, device=dev)
     compute = torch.cuda.current_stream()
     copy_stream = torch.cuda.Stream() if ingest else None
-    stream = compute.cuda_stream
+    # chunks exist to overlap the gather (and the H2D ingest) with the FFT; one GPU with resident input has neither
+    n_chunks = args.chunks if (world > 1 or ingest) else 1
+    # consecutive chunks are transformed ALTERNATELY ON TWO STREAMS (include/fsea.h: fsea_stream_create): chunk j + 1 ramps up
+    # under chunk j's drain; the stream that gathers and stitches (`compute`) waits for each chunk where it consumes it
+    lanes = [torch.cuda.Stream(), torch.cuda.Stream()] if n_chunks > 1 else None
+    issued = [0]
+
+    def launch_stream(first_of_step_dependency):
+        if lanes is None:
+            return compute
+        s = lanes[issued[0] % 2]
+        if issued[0] % n_chunks == 0 and first_of_step_dependency:
+            s.wait_stream(compute)                              # e.g. the zero fill of this step's image
+        issued[0] += 1
+        return s
 
     def make_tiles(a, b):                                       # tiles a..b-1 of the sweep, one launch
         s0, s1 = (a - lo) * tile_bytes, (b - lo) * tile_bytes
+        st = launch_stream(False)
         if ingest:
             with torch.cuda.stream(copy_stream):
                 iq[s0:s1].copy_(host_iq[s0:s1], non_blocking=True)
                 ready = torch.cuda.Event()
                 ready.record()
-            compute.wait_event(ready)
-        plan.exec_device(iq.data_ptr() + s0, (b - a) * rows, px.data_ptr() + (a - lo) * rows * n, flip=True, stream=stream)
+            st.wait_event(ready)
+        plan.exec_device(iq.data_ptr() + s0, (b - a) * rows, px.data_ptr() + (a - lo) * rows * n, flip=True, stream=st.cuda_stream)
+        if st is not compute:
+            compute.wait_stream(st)                             # the consumer (send / composite) runs on `compute`
         return px[a - lo: b - lo]
 
     def write_tiles(image, a, b):                               # rank 0's own tiles, straight into the stitched image
         s0 = (a - lo) * tile_bytes
+        st = launch_stream(True)
         if ingest:
             with torch.cuda.stream(copy_stream):
                 iq[s0:(b - lo) * tile_bytes].copy_(host_iq[s0:(b - lo) * tile_bytes], non_blocking=True)
                 ready = torch.cuda.Event()
                 ready.record()
-            compute.wait_event(ready)
+            st.wait_event(ready)
         plan.exec_tiled_device(iq.data_ptr() + s0, (b - a) * rows, image.data_ptr(), image.shape[0], image.shape[1], a * n,
-                               rows, n, flip=True, stream=stream)
+                               rows, n, flip=True, stream=st.cuda_stream)
+        if st is not compute:
+            compute.wait_stream(st)
+
+    stream = compute.cuda_stream
 
     def composite(image, tile, x):
         fsea.composite_max_device(image.data_ptr(), tile.data_ptr(), x, 0, n, rows, image.shape[1], image.shape[0], n,
@@ -255,9 +277,6 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     def composite_stack(image, stack, count, first_x):
         fsea.stitch_tiles_device(image.data_ptr(), stack.data_ptr(), count, first_x, n, n, rows, image.shape[1],
                                  device=dev.index, stream=stream)
-
-    # chunks exist to overlap the gather (and the H2D ingest) with the FFT; one GPU with resident input has neither
-    n_chunks = args.chunks if (world > 1 or ingest) else 1
 
     def step():
         return sweep.run_sweep(tiles, (rows, n), make_tiles, composite, dist=dist, torch=torch, device=dev,
@@ -419,12 +438,19 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
     rows = out[f_lo:f_hi] if rank == 0 else torch.empty((f_hi - f_lo, n), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def make_rows(a, b):
-        plan.exec_device(iq.data_ptr() + 2 * (a * hop - s_lo), b - a, rows.data_ptr() + 4 * n * (a - f_lo), flip=True,
-                         stream=stream)
-        return rows[a - f_lo: b - f_lo]
-
     n_chunks = args.chunks if world > 1 else 1
+    compute = torch.cuda.current_stream()
+    lanes = [torch.cuda.Stream(), torch.cuda.Stream()] if n_chunks > 1 else None   # consecutive chunks alternate (run_broad)
+    issued = [0]
+
+    def make_rows(a, b):
+        st = compute if lanes is None else lanes[issued[0] % 2]
+        issued[0] += 1
+        plan.exec_device(iq.data_ptr() + 2 * (a * hop - s_lo), b - a, rows.data_ptr() + 4 * n * (a - f_lo), flip=True,
+                         stream=st.cuda_stream)
+        if st is not compute:
+            compute.wait_stream(st)                             # the consumer (send / copy into place) runs on `compute`
+        return rows[a - f_lo: b - f_lo]
 
     def step():
         return sweep.run_stft(total_frames, n, make_rows, out, dist=dist, torch=torch, device=dev, n_chunks=n_chunks)

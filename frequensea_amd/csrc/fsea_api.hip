@@ -325,6 +325,7 @@ unsigned *counter_slot(fsea_plan *p, hipStream_t s, int *index, bool *record) {
     }
     fsea_plan::CtrSlot &c = p->slots[pick];
     if (capturing) c.captured = true;
+    else if (c.captured) c.captured = c.pending = false;  // the stream is launching outside a capture again: the slot is an ordinary one
     if (!capturing && !c.ev) {
         if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     }
@@ -348,6 +349,15 @@ int launch(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, int fli
             return fail(FSEA_EINVAL, "fft_size %d runs through %s: the frequency-shifted and the tiled "
                                      "entry points exist for the power-of-two sizes from 32 to 16384 only", p->n,
                         p->blu_m ? "Bluestein's algorithm" : "the four-step decomposition");
+        }
+        if (s != nullptr) {  // five to ten launches through the plan's own work buffers, ordered by events: not capturable
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive) {
+                return fail(FSEA_EINVAL, "fft_size %d runs through %s, whose launches cannot be captured into a graph (include/fsea.h); "
+                                         "only the powers of two from 32 to 16384 can", p->n,
+                            p->blu_m ? "Bluestein's algorithm" : "the four-step decomposition");
+            }
+            (void)hipGetLastError();
         }
         std::lock_guard<std::mutex> lock(p->work_mu);
         if (!p->work_ev) FSEA_HIP(hipEventCreateWithFlags(&p->work_ev, hipEventDisableTiming));
@@ -1268,6 +1278,35 @@ int fsea_copy_to_device(int device, void *d_dst, const void *src, size_t bytes) 
 int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes) {
     FSEA_ON_DEVICE(device);
     FSEA_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return FSEA_OK;
+}
+
+int fsea_stream_create(int device, void **stream) {
+    if (!stream) return fail(FSEA_EINVAL, "stream out-pointer is NULL");
+    *stream = nullptr;
+    FSEA_ON_DEVICE(device);
+    hipStream_t s = nullptr;
+    FSEA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return FSEA_OK;
+}
+
+int fsea_stream_destroy(int device, void *stream) {
+    if (!stream) return FSEA_OK;
+    FSEA_ON_DEVICE(device);
+    FSEA_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return FSEA_OK;
+}
+
+int fsea_copy_to_device_async(int device, void *d_dst, const void *src, size_t bytes, void *stream) {
+    FSEA_ON_DEVICE(device);
+    FSEA_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return FSEA_OK;
+}
+
+int fsea_copy_to_host_async(int device, void *dst, const void *d_src, size_t bytes, void *stream) {
+    FSEA_ON_DEVICE(device);
+    FSEA_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     return FSEA_OK;
 }
 

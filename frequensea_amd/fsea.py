@@ -33,6 +33,7 @@ EXPORTS = [
     "fsea_history_create", "fsea_history_destroy", "fsea_history_push_u8_host", "fsea_history_push_f64_host",
     "fsea_history_shift", "fsea_history_get_f64",
     "fsea_plan_set_window", "fsea_plan_window_form", "fsea_window_fill",
+    "fsea_stream_create", "fsea_stream_destroy", "fsea_copy_to_device_async", "fsea_copy_to_host_async",
 ]
 # include/fsea_tune.h: only libfsea_hip_tune.so (scripts/tune.py and friends) has these
 TUNE_EXPORTS = ["fsea_plan_create_variant", "fsea_time_exec_u8_device", "fsea_time_exec_u8_rotating",

@@ -11,6 +11,9 @@
  * (:56-59, SAMPLE_BLOCKS_TO_SKIP) and the newest row is image row 0 (:72-74).
  * The per-sample loops and FFTW are one fused GPU launch per centre frequency (include/fsea.h), and the three host
  * stages overlap (pipeline.h): capture k + 1 is being read and the PNG of capture k - 1 encoded while k is on the GPU.
+ * Consecutive captures go to the GPU ALTERNATELY ON TWO STREAMS with double-buffered device memory (round 4): upload,
+ * gate, transform and download of capture k + 1 are queued while capture k is still draining -- the streaming shape of
+ * the reference's receive callback (c/fft-batch.c:54-102: a transfer in, a row out) at the granularity of a capture.
  *
  * usage: fsea-fft-batch [--broad] [--rows H] [--fft N] [--skip K] [--out DIR] [--device D] [--timing]
  *                       FREQ_MHZ=capture.raw [FREQ_MHZ=capture.raw ...]
@@ -99,9 +102,19 @@ int main(int argc, char **argv) {
     if (fsea_plan_create(&plan, fft_size, fft_size, broad ? FSEA_MODE_DB5_U8_DCFIX : FSEA_MODE_DB10_U8, device) != 0) {
         die("fsea_plan_create");
     }
-    void *d_iq = NULL, *d_px = NULL;
-    if (fsea_device_alloc(device, (size_t)rows_wanted * row_in, &d_iq) != 0) die("fsea_device_alloc");
-    if (fsea_device_alloc(device, (size_t)rows_wanted * (size_t)fft_size, &d_px) != 0) die("fsea_device_alloc");
+    /* two GPU slots: stream + device buffers each; capture k uses slot (number of captures sent to the GPU so far) % 2 */
+    typedef struct {
+        void *stream, *d_iq, *d_px;
+        int busy, rows, job;      /* busy: a transform + download is queued on `stream`, to become PNG job `job` */
+        char file_name[512];
+    } gpu_slot;
+    gpu_slot slot[2];
+    memset(slot, 0, sizeof(slot));
+    for (int k = 0; k < 2; k++) {
+        if (fsea_stream_create(device, &slot[k].stream) != 0) die("fsea_stream_create");
+        if (fsea_device_alloc(device, (size_t)rows_wanted * row_in, &slot[k].d_iq) != 0) die("fsea_device_alloc");
+        if (fsea_device_alloc(device, (size_t)rows_wanted * (size_t)fft_size, &slot[k].d_px) != 0) die("fsea_device_alloc");
+    }
     void *packed[2] = {NULL, NULL}, *pixels[2] = {NULL, NULL};
     for (int k = 0; k < 2; k++) {
         if (fsea_host_alloc((size_t)rows_wanted * row_in, &packed[k]) != 0) die("fsea_host_alloc");
@@ -124,26 +137,39 @@ int main(int argc, char **argv) {
 
     const double t_loop = stage_clock();
     double gpu_s = 0.0;
-    for (int item = 0; item < argc - first_capture; item++) {
+    int sent = 0;        /* captures handed to the GPU = PNG jobs started */
+    int fatal = 0;
+    for (int item = 0; item < argc - first_capture && !fatal; item++) {
         const double freq_mhz = atof(argv[first_capture + item]);
         printf("Frequency: %.4f MHz\n", freq_mhz);
         uint8_t *iq = NULL;
         int rows = 0;
         const int rc = capture_reader_take(&reader, item, &iq, &rows);
-        if (rc > 0) return EXIT_FAILURE;      /* unreadable capture or short read: fatal, as in the reference */
+        if (rc > 0) {                          /* unreadable capture or short read: fatal, as in the reference -- but the */
+            fatal = 1;                         /* PNGs of the captures before it are completed first (below) */
+            capture_reader_release(&reader, item);
+            break;
+        }
         if (rc < 0) {                          /* too few transfers: reported by the reader, next capture */
             capture_reader_release(&reader, item);
             continue;
         }
+        gpu_slot *g = &slot[sent & 1];
         const double t_gpu = stage_clock();
-        if (fsea_copy_to_device(device, d_iq, iq, (size_t)rows * row_in) != 0) die("fsea_copy_to_device");
+        if (g->busy) {                         /* what this slot did two captures ago: its pixels are in the writer's buffer */
+            if (fsea_stream_synchronize(plan, g->stream) != 0) die("fsea_stream_synchronize");
+            png_writer_submit_job(&writer, g->job, g->file_name, fft_size, g->rows);
+            g->busy = 0;
+        }
+        if (fsea_copy_to_device_async(device, g->d_iq, iq, (size_t)rows * row_in, g->stream) != 0) die("fsea_copy_to_device_async");
+        if (fsea_stream_synchronize(plan, g->stream) != 0) die("fsea_stream_synchronize");   /* (the other slot keeps running) */
         capture_reader_release(&reader, item); /* the reader may load capture item + 2 into this buffer */
 
         if (broad && rows >= EVALUATE_ROWS) {
             /* the first 100 rows received are the last 100 rows of the newest-first stack */
             double avg = 0.0;
-            const char *oldest = (const char *)d_iq + (size_t)(rows - EVALUATE_ROWS) * row_in;
-            if (fsea_mean_magnitude_u8_device(plan, oldest, EVALUATE_ROWS, 1, &avg, NULL) != 0) die("gate");
+            const char *oldest = (const char *)g->d_iq + (size_t)(rows - EVALUATE_ROWS) * row_in;
+            if (fsea_mean_magnitude_u8_device(plan, oldest, EVALUATE_ROWS, 1, &avg, g->stream) != 0) die("gate");
             printf("\n(Average power: %.2f)\n", avg);
             if (avg < 1.1) {
                 printf("Not interesting. Skipping...\n");
@@ -151,26 +177,35 @@ int main(int argc, char **argv) {
                 continue;
             }
         }
-        if (fsea_exec_u8_device(plan, d_iq, (size_t)rows, 1, d_px, NULL) != 0) die("fsea_exec_u8_device");
-        if (fsea_stream_synchronize(plan, NULL) != 0) die("fsea_stream_synchronize");
+        uint8_t *px = png_writer_acquire_job(&writer, sent); /* waits for the PNG written from this buffer two jobs ago */
+        if (fsea_exec_u8_device(plan, g->d_iq, (size_t)rows, 1, g->d_px, g->stream) != 0) die("fsea_exec_u8_device");
+        if (fsea_copy_to_host_async(device, px, g->d_px, (size_t)rows * (size_t)fft_size, g->stream) != 0) die("fsea_copy_to_host_async");
         gpu_s += stage_clock() - t_gpu;
-        uint8_t *px = png_writer_acquire(&writer); /* waits for the PNG written from this buffer two captures ago */
-        const double t_down = stage_clock();
-        if (fsea_copy_to_host(device, px, d_px, (size_t)rows * (size_t)fft_size) != 0) die("fsea_copy_to_host");
-        gpu_s += stage_clock() - t_down;
-        char file_name[512];
         if (broad) {
-            snprintf(file_name, sizeof(file_name), "%s/broad-%.0f.png", out_dir, freq_mhz);
+            snprintf(g->file_name, sizeof(g->file_name), "%s/broad-%.0f.png", out_dir, freq_mhz);
         } else {
-            snprintf(file_name, sizeof(file_name), "%s/fft-%.4f.png", out_dir, freq_mhz);
+            snprintf(g->file_name, sizeof(g->file_name), "%s/fft-%.4f.png", out_dir, freq_mhz);
         }
-        png_writer_submit(&writer, file_name, fft_size, rows);
+        g->rows = rows;
+        g->job = sent;
+        g->busy = 1;
+        sent++;
     }
-    capture_reader_join(&reader);
-    if (png_writer_finish(&writer) != 0) return EXIT_FAILURE;
+    /* what is still in flight, older job first */
+    for (int k = 0; k < 2; k++) {
+        gpu_slot *g = &slot[(sent + k) & 1];
+        if (!g->busy) continue;
+        const double t_gpu = stage_clock();
+        if (fsea_stream_synchronize(plan, g->stream) != 0) die("fsea_stream_synchronize");
+        gpu_s += stage_clock() - t_gpu;
+        png_writer_submit_job(&writer, g->job, g->file_name, fft_size, g->rows);
+        g->busy = 0;
+    }
+    if (!fatal) capture_reader_join(&reader);
+    if (png_writer_finish(&writer) != 0 || fatal) return EXIT_FAILURE;
     if (timing) {
         const double wall = stage_clock() - t_loop;
-        printf("Stages busy: read %.3f s, GPU (upload, gate, FFT, download) %.3f s, PNG %.3f s; wall %.3f s for %d captures "
+        printf("Stages busy: read %.3f s, GPU (upload, gate, FFT and download queued on two streams; waits) %.3f s, PNG %.3f s; wall %.3f s for %d captures "
                "(one after the other: %.3f s)\n", reader.busy_s, gpu_s, writer.busy_s, wall, argc - first_capture,
                reader.busy_s + gpu_s + writer.busy_s);
     }
@@ -178,8 +213,11 @@ int main(int argc, char **argv) {
         fsea_host_free(packed[k]);
         fsea_host_free(pixels[k]);
     }
-    fsea_device_free(device, d_iq);
-    fsea_device_free(device, d_px);
+    for (int k = 0; k < 2; k++) {
+        fsea_device_free(device, slot[k].d_iq);
+        fsea_device_free(device, slot[k].d_px);
+        fsea_stream_destroy(device, slot[k].stream);
+    }
     fsea_plan_destroy(plan);
     return 0;
 }

@@ -64,13 +64,23 @@ typedef struct {
 } member_arg;
 
 /* Fatal conditions print and end the process (the reference's convention, c/fft-batch.c:41-47); a member
- * that merely returned would leave the others waiting in the next gather. */
+ * that merely returned would leave the others waiting in the next gather.  The tile PNGs that were already handed to
+ * a writer thread are completed first: an error in one capture must not truncate the image of an earlier one. */
+static png_writer *g_writers[MAX_MEMBERS];
+static pthread_mutex_t g_fatal_mu = PTHREAD_MUTEX_INITIALIZER;
+static void fatal_exit(void) {
+    pthread_mutex_lock(&g_fatal_mu); /* one thread ends the process; a second fatal error waits here until it has */
+    for (int m = 0; m < MAX_MEMBERS; m++) {
+        if (g_writers[m]) png_writer_drain(g_writers[m]);
+    }
+    exit(EXIT_FAILURE);
+}
 #define CHECK(ok, ...)                                                                            \
     do {                                                                                          \
         if (!(ok)) {                                                                              \
             fprintf(stderr, "fsea-fft-sweep: " __VA_ARGS__);                                      \
             fprintf(stderr, " (%s | %s)\n", fsea_last_error_string(), fsea_comm_last_error());    \
-            exit(EXIT_FAILURE);                                                                   \
+            fatal_exit();                                                                         \
         }                                                                                         \
     } while (0)
 
@@ -152,7 +162,9 @@ static void *member_main(void *argp) {
     const int mine = cfg->hi[me] - cfg->lo[me];
 
     fsea_plan *plan = NULL;
-    void *stream = NULL, *d_iq = NULL, *d_tiles = NULL, *d_inbox = NULL;
+    /* stream: tiles with an even index, the gathers and the composites; stream2: tiles with an odd index -- consecutive
+     * captures of a member go to its GPU alternately on two streams with double-buffered input (include/fsea.h) */
+    void *stream = NULL, *stream2 = NULL, *d_iq2[2] = {NULL, NULL}, *d_tiles = NULL, *d_inbox = NULL;
     void *packed[2] = {NULL, NULL}, *pixels[2] = {NULL, NULL};
     for (int k = 0; k < 2; k++) {
         CHECK(fsea_host_alloc((size_t)rows * row_in, &packed[k]) == 0 && fsea_host_alloc(tile_bytes, &pixels[k]) == 0,
@@ -169,10 +181,12 @@ static void *member_main(void *argp) {
     png_writer writer;
     CHECK(capture_reader_start(&reader, mine, member_loader, &rctx, (uint8_t *)packed[0], (uint8_t *)packed[1]) == 0 &&
           png_writer_start(&writer, (uint8_t *)pixels[0], (uint8_t *)pixels[1]) == 0, "member %d: reader / writer threads", me);
+    g_writers[me] = &writer;
     CHECK(fsea_plan_create(&plan, n, n, cfg->broad ? FSEA_MODE_DB5_U8_DCFIX : FSEA_MODE_DB10_U8, device) == 0,
           "member %d: fsea_plan_create", me);
-    CHECK(fsea_comm_stream_create(device, &stream) == 0, "member %d: stream", me);
-    CHECK(fsea_device_alloc(device, (size_t)rows * row_in, &d_iq) == 0, "member %d: alloc", me);
+    CHECK(fsea_comm_stream_create(device, &stream) == 0 && fsea_comm_stream_create(device, &stream2) == 0, "member %d: stream", me);
+    CHECK(fsea_device_alloc(device, (size_t)rows * row_in, &d_iq2[0]) == 0 &&
+          fsea_device_alloc(device, (size_t)rows * row_in, &d_iq2[1]) == 0, "member %d: alloc", me);
     CHECK(fsea_device_alloc(device, tile_bytes * (size_t)(mine > 0 ? mine : 1), &d_tiles) == 0, "member %d: alloc", me);
     if (me == 0) {
         CHECK(fsea_device_alloc(device, tile_bytes * (size_t)cfg->chunk * (size_t)cfg->n_members, &d_inbox) == 0,
@@ -186,19 +200,21 @@ static void *member_main(void *argp) {
         for (int k = c_lo; k < c_hi; k++) {
             const capture *cap = &cfg->captures[cfg->lo[me] + k];
             char *tile = (char *)d_tiles + (size_t)k * tile_bytes;
+            void *const st = (k & 1) ? stream2 : stream;
+            void *const d_iq = d_iq2[k & 1];
             int got_rows = 0, keep = 1;
             uint8_t *iq = NULL;
             printf("Frequency: %.4f MHz\n", cap->freq_mhz);
             CHECK(capture_reader_take(&reader, k, &iq, &got_rows) == 0, "member %d: %s", me, cap->path);
-            /* the stream may still read d_iq for the previous tile */
-            CHECK(fsea_stream_synchronize(plan, stream) == 0, "member %d: sync", me);
+            /* this slot's stream may still read its d_iq for the tile two captures ago (the other slot keeps running) */
+            CHECK(fsea_stream_synchronize(plan, st) == 0, "member %d: sync", me);
             CHECK(fsea_copy_to_device(device, d_iq, iq, (size_t)rows * row_in) == 0, "member %d: upload", me);
             capture_reader_release(&reader, k); /* the reader may load this member's capture k + 2 now */
             if (cfg->broad && rows >= EVALUATE_ROWS) {
                 /* the first 100 rows received are the last 100 rows of the newest-first stack (c/fft-batch-broad.c:81-98) */
                 double avg = 0.0;
                 const char *oldest = (const char *)d_iq + (size_t)(rows - EVALUATE_ROWS) * row_in;
-                CHECK(fsea_mean_magnitude_u8_device(plan, oldest, EVALUATE_ROWS, 1, &avg, stream) == 0, "member %d: gate", me);
+                CHECK(fsea_mean_magnitude_u8_device(plan, oldest, EVALUATE_ROWS, 1, &avg, st) == 0, "member %d: gate", me);
                 printf("\n(Average power: %.2f)\n", avg);
                 if (avg < 1.1) {
                     printf("Not interesting. Skipping...\n");
@@ -206,7 +222,7 @@ static void *member_main(void *argp) {
                 }
             }
             if (keep) {
-                CHECK(fsea_exec_u8_device(plan, d_iq, (size_t)rows, 1, tile, stream) == 0, "member %d: exec", me);
+                CHECK(fsea_exec_u8_device(plan, d_iq, (size_t)rows, 1, tile, st) == 0, "member %d: exec", me);
             } else {
                 uint8_t *zero = png_writer_acquire(&writer); /* (a free pixel buffer; nothing is submitted) */
                 memset(zero, 0, tile_bytes); /* an all-zero tile changes nothing under max */
@@ -214,7 +230,7 @@ static void *member_main(void *argp) {
             }
             if (keep && cfg->write_tiles) {
                 char file_name[600];
-                CHECK(fsea_stream_synchronize(plan, stream) == 0, "member %d: sync", me);
+                CHECK(fsea_stream_synchronize(plan, st) == 0, "member %d: sync", me);
                 uint8_t *px = png_writer_acquire(&writer); /* waits for the PNG encoded from this buffer two tiles ago */
                 CHECK(fsea_copy_to_host(device, px, tile, tile_bytes) == 0, "member %d: download", me);
                 if (cfg->broad) snprintf(file_name, sizeof(file_name), "%s/broad-%.0f.png", cfg->out_dir, cap->freq_mhz);
@@ -222,6 +238,8 @@ static void *member_main(void *argp) {
                 png_writer_submit(&writer, file_name, n, rows);
             }
         }
+        /* the chunk's odd tiles are complete before the gather reads them on `stream` */
+        CHECK(fsea_stream_synchronize(plan, stream2) == 0, "member %d: sync", me);
         /* gather chunk j: member m's tiles land at slot m of the root's inbox.  The inbox is reused per
          * chunk: the transfers are queued on the root's stream behind the composites of chunk j - 1. */
         size_t bytes[MAX_MEMBERS], offsets[MAX_MEMBERS];
@@ -251,15 +269,18 @@ static void *member_main(void *argp) {
     /* all transfers complete, all source tiles free again */
     CHECK(fsea_comm_barrier(cfg->comm, me, stream) == 0, "member %d: barrier", me);
     capture_reader_join(&reader);
+    g_writers[me] = NULL;
     CHECK(png_writer_finish(&writer) == 0, "member %d: a tile PNG could not be written", me);
     for (int k = 0; k < 2; k++) {
         fsea_host_free(packed[k]);
         fsea_host_free(pixels[k]);
     }
-    fsea_device_free(device, d_iq);
+    fsea_device_free(device, d_iq2[0]);
+    fsea_device_free(device, d_iq2[1]);
     fsea_device_free(device, d_tiles);
     fsea_device_free(device, d_inbox);
     fsea_comm_stream_destroy(device, stream);
+    fsea_comm_stream_destroy(device, stream2);
     fsea_plan_destroy(plan);
     return NULL;
 }

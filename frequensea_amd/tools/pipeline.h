@@ -25,23 +25,23 @@ typedef struct {
     int full[2];
 } slot_ring;
 
-static double stage_clock(void) {
+static inline double stage_clock(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static void ring_init(slot_ring *r) {
+static inline void ring_init(slot_ring *r) {
     pthread_mutex_init(&r->mu, NULL);
     pthread_cond_init(&r->cv, NULL);
     r->full[0] = r->full[1] = 0;
 }
-static void ring_wait(slot_ring *r, int slot, int want_full) {
+static inline void ring_wait(slot_ring *r, int slot, int want_full) {
     pthread_mutex_lock(&r->mu);
     while (r->full[slot] != want_full) pthread_cond_wait(&r->cv, &r->mu);
     pthread_mutex_unlock(&r->mu);
 }
-static void ring_set(slot_ring *r, int slot, int full) {
+static inline void ring_set(slot_ring *r, int slot, int full) {
     pthread_mutex_lock(&r->mu);
     r->full[slot] = full;
     pthread_cond_broadcast(&r->cv);
@@ -61,7 +61,7 @@ typedef struct {
     double busy_s; /* seconds spent loading (--timing) */
 } capture_reader;
 
-static void *capture_reader_main(void *p) {
+static inline void *capture_reader_main(void *p) {
     capture_reader *r = (capture_reader *)p;
     for (int i = 0; i < r->n_items; i++) {
         const int s = i & 1;
@@ -74,7 +74,7 @@ static void *capture_reader_main(void *p) {
     }
     return NULL;
 }
-static int capture_reader_start(capture_reader *r, int n_items, capture_loader load, void *ctx, uint8_t *b0, uint8_t *b1) {
+static inline int capture_reader_start(capture_reader *r, int n_items, capture_loader load, void *ctx, uint8_t *b0, uint8_t *b1) {
     ring_init(&r->ring);
     r->busy_s = 0.0;
     r->n_items = n_items;
@@ -85,15 +85,15 @@ static int capture_reader_start(capture_reader *r, int n_items, capture_loader l
     return pthread_create(&r->thread, NULL, capture_reader_main, r);
 }
 /* item i (in order): waits until it is loaded; *buffer stays valid until capture_reader_release(i) */
-static int capture_reader_take(capture_reader *r, int item, uint8_t **buffer, int *rows) {
+static inline int capture_reader_take(capture_reader *r, int item, uint8_t **buffer, int *rows) {
     const int s = item & 1;
     ring_wait(&r->ring, s, 1);
     *buffer = r->buffer[s];
     *rows = r->rows[s];
     return r->rc[s];
 }
-static void capture_reader_release(capture_reader *r, int item) { ring_set(&r->ring, item & 1, 0); }
-static void capture_reader_join(capture_reader *r) { pthread_join(r->thread, NULL); }
+static inline void capture_reader_release(capture_reader *r, int item) { ring_set(&r->ring, item & 1, 0); }
+static inline void capture_reader_join(capture_reader *r) { pthread_join(r->thread, NULL); }
 
 /* ---- writer: PNGs are encoded and written from pixel buffer k % 2 of job k ---- */
 typedef struct {
@@ -106,7 +106,7 @@ typedef struct {
     double busy_s; /* seconds spent encoding and writing (--timing) */
 } png_writer;
 
-static void *png_writer_main(void *p) {
+static inline void *png_writer_main(void *p) {
     png_writer *w = (png_writer *)p;
     for (int k = 0;; k++) {
         const int s = k & 1;
@@ -119,7 +119,7 @@ static void *png_writer_main(void *p) {
     }
     return NULL;
 }
-static int png_writer_start(png_writer *w, uint8_t *p0, uint8_t *p1) {
+static inline int png_writer_start(png_writer *w, uint8_t *p0, uint8_t *p1) {
     ring_init(&w->ring);
     w->pixels[0] = p0;
     w->pixels[1] = p1;
@@ -128,12 +128,12 @@ static int png_writer_start(png_writer *w, uint8_t *p0, uint8_t *p1) {
     return pthread_create(&w->thread, NULL, png_writer_main, w);
 }
 /* the pixel buffer of the next job, free to be filled (waits for the job that used it two jobs ago) */
-static uint8_t *png_writer_acquire(png_writer *w) {
+static inline uint8_t *png_writer_acquire(png_writer *w) {
     const int s = w->jobs & 1;
     ring_wait(&w->ring, s, 0);
     return w->pixels[s];
 }
-static void png_writer_submit(png_writer *w, const char *name, int width, int height) {
+static inline void png_writer_submit(png_writer *w, const char *name, int width, int height) {
     const int s = w->jobs & 1;
     snprintf(w->name[s], sizeof(w->name[s]), "%s", name);
     w->width[s] = width;
@@ -141,8 +141,28 @@ static void png_writer_submit(png_writer *w, const char *name, int width, int he
     w->jobs++;
     ring_set(&w->ring, s, 1);
 }
+/* The same two calls by job number, for a caller that fills the buffer of job k + 1 before it submits job k (two batches
+ * in flight on two streams): job k uses pixel buffer k % 2; submissions must still be made in job order. */
+static inline uint8_t *png_writer_acquire_job(png_writer *w, int job) {
+    ring_wait(&w->ring, job & 1, 0);
+    return w->pixels[job & 1];
+}
+static inline void png_writer_submit_job(png_writer *w, int job, const char *name, int width, int height) {
+    const int s = job & 1;
+    snprintf(w->name[s], sizeof(w->name[s]), "%s", name);
+    w->width[s] = width;
+    w->height[s] = height;
+    w->jobs = job + 1;
+    ring_set(&w->ring, s, 1);
+}
+/* Waits until no submitted PNG is pending (both buffers empty); callable from any thread -- the fatal paths use it so that
+ * an error in one capture does not truncate the PNG of an earlier, successfully processed one. */
+static inline void png_writer_drain(png_writer *w) {
+    ring_wait(&w->ring, 0, 0);
+    ring_wait(&w->ring, 1, 0);
+}
 /* waits for every submitted PNG; returns non-zero if one of them could not be written */
-static int png_writer_finish(png_writer *w) {
+static inline int png_writer_finish(png_writer *w) {
     const int s = w->jobs & 1;
     ring_wait(&w->ring, s, 0);
     w->height[s] = -1;

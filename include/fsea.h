@@ -51,7 +51,12 @@ typedef struct fsea_history fsea_history;
 enum {
     /* sqrt(re^2+im^2) as f32, bin n/2 := bin n/2-1 (src/nrf.c:619-630). */
     FSEA_MODE_MAG_F32 = 0,
-    /* clamp_u8(trunc(10*log10(re^2+im^2+1e-20)*10)) (c/fft-batch.c:83-94). */
+    /* clamp_u8(trunc(10*log10(re^2+im^2+1e-20)*10)) (c/fft-batch.c:83-94).  The f32 kernels form d = 100 log10(p) and
+     * convert with v_cvt_pk_u8_f32 (round to nearest even) after lowering d by 0.5 - 2^-25: trunc(d) except for d within
+     * ~8e-6 above an odd integer, where the pixel comes out one grey level low -- about one pixel in 2.5e5, inside the
+     * stated pixel tolerance (exact on >= 99.9 %, +-1 elsewhere: the f32 logarithm itself moves more pixels than that
+     * across an integer boundary); tests/test_emu_kernels.py::test_biased_pixel_rounding_equals_truncation_on_a_dense_sweep pins it.  The Bluestein /
+     * four-step sizes truncate in a plain epilogue kernel. */
     FSEA_MODE_DB10_U8 = 1,
     /* same with *5 and pixel n/2 := pixel n/2-1 (c/fft-batch-broad.c:106-121). */
     FSEA_MODE_DB5_U8_DCFIX = 2,
@@ -164,7 +169,9 @@ int fsea_plan_set_unit_distribution(fsea_plan *plan, int policy);
  * being captured into a hipGraph nothing but the kernel is enqueued
  * (launch-bound consumers: tests/test_gpu_parity.py::test_launches_can_be_captured_into_a_hip_graph); a captured
  * launch keeps the ticket-counter slot of the stream it was captured on: replay one instance of such a graph at a
- * time. */
+ * time.  A stream that launches outside a capture again gets an ordinary slot back; at most 64 distinct streams may
+ * hold captured launches of one plan at a time (fsea_plan_reset releases them all).  Plans of the sizes without a
+ * kernel of their own (Bluestein / four-step) refuse a capturing stream with FSEA_EINVAL. */
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
                         void *d_out, void *stream);
 
@@ -261,6 +268,18 @@ int fsea_copy_to_device(int device, void *d_dst, const void *src, size_t bytes);
 int fsea_copy_to_host(int device, void *dst, const void *d_src, size_t bytes);
 /* Waits for `stream` (NULL = the null stream) on the plan's device. */
 int fsea_stream_synchronize(fsea_plan *plan, void *stream);
+
+/* Streams and asynchronous copies for C callers (a hipStream_t as void*, non-blocking with respect to the null stream).
+ * A consumer of independent batches -- captures of a sweep, blocks of a stream -- submits consecutive batches
+ * ALTERNATELY ON TWO STREAMS with double-buffered device memory: upload, transform and download of batch k + 1 overlap
+ * the drain of batch k, and the ramp and tail of each launch (a few microseconds in which the chip is not full) are
+ * covered by its neighbour: +8...12 % on resident batches (bench.py: extra.two_stream_*), more when copies are in the
+ * loop.  INTEGRATION.md section 2 shows the pattern; fsea-fft-batch and fsea-fft-sweep use it.  Host memory should come
+ * from fsea_host_alloc (pinned), or the copies fall back to staged, synchronous ones. */
+int fsea_stream_create(int device, void **stream);
+int fsea_stream_destroy(int device, void *stream);
+int fsea_copy_to_device_async(int device, void *d_dst, const void *src, size_t bytes, void *stream);
+int fsea_copy_to_host_async(int device, void *dst, const void *d_src, size_t bytes, void *stream);
 
 /* Recovery after an aborted launch (device fault, killed context): waits for the device and
  * re-zeroes the plan's internal frame-distribution counters.  Not needed in normal operation. */
