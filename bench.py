@@ -313,19 +313,23 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     # written into the stitched image
     if ingest:
         iq.copy_(host_iq)
-    kms = []
-    for rep in range(max(3, repeats)):
-        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        k0.record()
-        for _ in range(10):
+    def kernel_only(count):
+        for _ in range(count):
             if rank == 0 and not args.no_fused_stitch:
                 plan.exec_tiled_device(iq.data_ptr(), (hi - lo) * rows, img.data_ptr(), img.shape[0], img.shape[1], lo * n,
                                        rows, n, flip=True, stream=stream)
             else:
                 plan.exec_device(iq.data_ptr(), (hi - lo) * rows, px.data_ptr(), flip=True, stream=stream)
+    kernel_only(20)                                             # (the chip idled while the host checked the image)
+    torch.cuda.synchronize()
+    kms = []
+    for rep in range(max(3, repeats)):
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        kernel_only(steps)
         k1.record()
         torch.cuda.synchronize()
-        kms.append(k0.elapsed_time(k1) / 10)
+        kms.append(k0.elapsed_time(k1) / steps)
     kernel_ms = float(np.median(kms))
     # one GPU, resident captures: consecutive sweeps issued alternately on two streams, each with its own image -- one
     # launch's drain under the next one's ramp, what a double-buffered consumer of independent sweeps gets

@@ -7,7 +7,8 @@
 #      stitched image must equal the max-composite of fsea-fft-batch's tiles made on one GPU; if RCCL cannot initialise
 #      the tool falls back to the "copy" backend with a loud line (fsea_comm.hip) and this script says so
 #   2. bench.py at 1, 2, 4 ... N ranks: the headline (frames sharded, no collective), the fft-batch-broad sweep with
-#      resident and with ingested captures, the halo-sharded 16384-point stream -- every line carries its regime in `config`
+#      resident and with ingested captures (its chunks alternate on two streams per rank), the halo-sharded 16384-point
+#      stream, rectangular and with the fused Hann taper -- every line carries its regime and window in `config`
 # Every step runs under `timeout`; nothing can hang the node.
 # Usage: bash scripts/multi_gpu_check.sh [N] [--dry-run] [--log FILE]
 #   --dry-run   print the commands instead of running them (no GPU needed; tests/test_host_api.py checks the plumbing)
@@ -115,7 +116,7 @@ fi
 port=29600
 n=1
 while [ $n -le "$N" ]; do
-  for wl in "headline|" "broad-resident|--workload broad --regime resident" "broad-ingest|--workload broad --regime ingest" "stft-stream|--workload stft16384stream"; do
+  for wl in "headline|" "headline-hann|--window hann" "broad-resident|--workload broad --regime resident" "broad-ingest|--workload broad --regime ingest" "stft-stream|--workload stft16384stream" "stft-stream-hann|--workload stft16384stream --window hann"; do
     name=${wl%%|*}; args=${wl#*|}
     port=$((port + 1))
     if [ $n -eq 1 ]; then

@@ -19,7 +19,8 @@ def test_multi_gpu_first_contact_kit_plumbing(tmp_path):
     assert "FSEA_COMM_BACKEND=copy frequensea_amd/bin/fsea-fft-sweep --broad --devices 0-7" in out
     assert out.count("660=") >= 3 and "750=" in out                     # 2 * 8 + 3 = 19 captures, 660 ... 750 MHz
     for n in (2, 4, 8):
-        for wl in ("", " --workload broad --regime resident", " --workload broad --regime ingest", " --workload stft16384stream"):
+        for wl in ("", " --window hann", " --workload broad --regime resident", " --workload broad --regime ingest",
+                   " --workload stft16384stream", " --workload stft16384stream --window hann"):
             want = "--nproc-per-node %d --master-addr 127.0.0.1" % n
             line = [ln for ln in out.splitlines() if want in ln and ln.rstrip().endswith(("--no-cpu-baseline" + wl).strip())]
             assert line, (n, wl)
