@@ -12,7 +12,7 @@ rocprofv3 -L > $OUT/counters_list.txt 2>&1
 run() {  # name, counters...
   name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o pmc --output-format csv -- \
-    python $R/bench.py --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-extra --workload $WL > $OUT/$name.json 2> $OUT/$name.err
+    python $R/bench.py --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-extra --workload $WL $PMC_EXTRA > $OUT/$name.json 2> $OUT/$name.err
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 $R/scripts/pmc_summary.py $f > $OUT/$name.summary.txt; cat $OUT/$name.summary.txt; rm -f $f; else echo "no counter file for $name"; tail -3 $OUT/$name.err; fi
 }

@@ -44,9 +44,10 @@ d_in = dev_alloc(host.nbytes)
 fsea._check(L.fsea_copy_to_device(0, d_in, host.ctypes.data, host.nbytes))
 d_out = [dev_alloc(4 * MAX_IN) for _ in streams]   # f32 rows of a non-overlapped launch fit; others are clipped below
 plans = {}
+WINDOWS = {}                                       # (name, n) -> the float32 weights handed to fsea_plan_set_window
 
 
-def rows_numpy(offset_bytes, frame, n, hop, flip, mode, shift=None):
+def rows_numpy(offset_bytes, frame, n, hop, flip, mode, shift=None, window=None):
     raw = host[offset_bytes + 2 * frame * hop: offset_bytes + 2 * frame * hop + 2 * n]
     u = (raw ^ np.uint8(0x80 if flip else 0)).astype(np.float64).reshape(n, 2) / 256.0
     y = u[:, 0] + 1j * u[:, 1]
@@ -54,6 +55,8 @@ def rows_numpy(offset_bytes, frame, n, hop, flip, mode, shift=None):
         m_idx = frame * hop + np.arange(n)
         y = y * np.exp(2j * np.pi * (shift[1] + m_idx * shift[0])) + 0.5 * (1 + 1j)
     x = y * (1.0 - 2.0 * (np.arange(n) & 1))
+    if window is not None:                         # the taper beside the (-1)^n (fsea_plan_set_window)
+        x = x * WINDOWS[(window, n)].astype(np.float64)
     X = np.fft.fft(x)
     mag = np.abs(X)
     if mode == 0:
@@ -167,7 +170,7 @@ while time.time() < t_end:
     si = int(rng.integers(len(streams)))
     if pending[si] is not None:                    # verify what this stream ran last, then reuse its buffer
         assert hip.hipStreamSynchronize(streams[si]) == 0
-        n, nf, hop, flip, mode, off, tiled, shape, shift = pending[si]
+        n, nf, hop, flip, mode, off, tiled, shape, shift, wname = pending[si]
         dt = {0: np.float32, 1: np.uint8, 2: np.uint8, 3: np.complex64, 4: np.float32, 5: np.float32}[mode]
         # sizes / modes whose rows leave in 16-byte stores (four adjacent f32 bins or two complex bins per lane): sample more
         wide = (mode in (0, 4, 5) and n in (64, 128, 2048)) or (mode == 3 and n in (32, 64, 128, 256, 512, 2048, 4096))
@@ -181,7 +184,7 @@ while time.time() < t_end:
             else:
                 src = d_out[si].value + f * n * row.itemsize
             fsea._check(L.fsea_copy_to_host(0, row.ctypes.data, ctypes.c_void_p(src), row.nbytes))
-            want = rows_numpy(off, f, n, hop, flip, mode, shift)
+            want = rows_numpy(off, f, n, hop, flip, mode, shift, wname)
             if shift is not None and mode in (0, 2):   # the restored offset sits in bin N/2, which these modes overwrite
                 pass
             if mode in (1, 2):
@@ -223,13 +226,19 @@ while time.time() < t_end:
         nf = int(min(nf_max, max(nf, (1 << 23) // n)))
     flip = bool(rng.integers(2))
     off = 16 * int(rng.integers(0, 2048))
-    key = (n, hop, mode)
+    # a plan with a taper window (fused into pass 0; centred form for "hann", offset-binary form for "noise") now and then
+    wname = None if (anysize or rng.random() >= 0.2) else str(rng.choice(["hann", "noise"]))
+    key = (n, hop, mode, wname)
     if key not in plans:
         plans[key] = fsea.Plan(n, hop=hop, mode=mode)
+        if wname:
+            if (wname, n) not in WINDOWS:
+                WINDOWS[(wname, n)] = fsea.window("hann", n) if wname == "hann" else np.random.default_rng(n).uniform(-1, 2, n).astype(np.float32)
+            plans[key].set_window(WINDOWS[(wname, n)])
     plan = plans[key]
     plan.set_unit_distribution(int(rng.integers(3)))
     tiled, shape, shift = False, None, None
-    if rng.random() < 0.12 and not anysize:        # the frequency shifter fused into the load (fsea_exec_u8_shifted_device)
+    if rng.random() < 0.12 and not anysize and not wname:        # the frequency shifter fused into the load (fsea_exec_u8_shifted_device)
         shift = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0, 1)))
         plan.exec_shifted_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], shift[0], shift[1], flip=flip,
                                  stream=streams[si].value)
@@ -245,7 +254,7 @@ while time.time() < t_end:
                                flip=flip, stream=streams[si].value)
     else:
         plan.exec_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], flip=flip, stream=streams[si].value)
-    pending[si] = (n, nf, hop, flip, mode, off, tiled, shape, shift)
+    pending[si] = (n, nf, hop, flip, mode, off, tiled, shape, shift, wname)
     launches += 1
 for s in streams:
     assert hip.hipStreamSynchronize(s) == 0
