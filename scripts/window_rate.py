@@ -47,7 +47,7 @@ def main():
             want = np.abs(np.fft.fft(rows * w.astype(np.float64), axis=1))
             want[:, n // 2] = want[:, n // 2 - 1]
             plans = [("rect", fsea.Plan(n, hop=hop, mode=MODE))]
-            for var in ("", "w1", "w2"):
+            for var in (None, "w1", "w2"):     # None = the product plan (its mode's configuration of the size)
                 try:
                     p = fsea.Plan(n, hop=hop, mode=MODE, variant=var)
                 except fsea.FseaError:
