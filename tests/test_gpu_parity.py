@@ -1483,6 +1483,84 @@ def test_launches_can_be_captured_into_a_hip_graph():
         plan.close()
 
 
+def test_windowed_launches_capture_too_and_the_anysize_paths_refuse_a_capturing_stream():
+    """A windowed plan's launch is one kernel as well (replayed rows equal the direct ones); a plan of a size without a
+    kernel of its own (Bluestein: several launches through plan-owned work buffers, ordered by events) refuses a
+    capturing stream with a clear FSEA_EINVAL instead of an opaque HIP error."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, nf = 4096, 64
+    plan = fsea.Plan(n)
+    plan.set_window("hann")
+    iq = torch.from_numpy(synth_iq(81, 2 * nf * n).copy()).to(dev)
+    out = torch.zeros(nf * n, dtype=torch.float32, device=dev)
+    plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = out.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    del graph
+    plan.close()
+    odd = fsea.Plan(1000, hop=1000)
+    iq2 = torch.from_numpy(synth_iq(82, 2 * 8 * 1000).copy()).to(dev)
+    out2 = torch.zeros(8 * 1000, dtype=torch.float32, device=dev)
+    odd.exec_device(iq2.data_ptr(), 8, out2.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)   # works outside a capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(fsea.FseaError, match="cannot be captured"):
+        with torch.cuda.graph(graph, stream=side):
+            odd.exec_device(iq2.data_ptr(), 8, out2.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    odd.close()
+
+
+def test_streams_and_asynchronous_copies_of_the_c_abi():
+    """fsea_stream_create + fsea_copy_to_device_async / fsea_copy_to_host_async: the two-stream pattern of INTEGRATION.md
+    section 2 through ctypes -- batches alternate between two streams with their own device buffers, pinned host memory."""
+    L = fsea.hip_lib()
+    n, nf, batches = 2048, 300, 6
+    plan = fsea.Plan(n, mode=fsea.MODE_DB10_U8)
+    vp = ctypes.c_void_p
+    L.fsea_stream_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.fsea_stream_destroy.argtypes = [ctypes.c_int, vp]
+    L.fsea_copy_to_device_async.argtypes = [ctypes.c_int, vp, vp, ctypes.c_size_t, vp]
+    L.fsea_copy_to_host_async.argtypes = [ctypes.c_int, vp, vp, ctypes.c_size_t, vp]
+    slots = []
+    for k in range(2):
+        st = vp()
+        fsea._check(L.fsea_stream_create(0, ctypes.byref(st)))
+        slots.append((st, DeviceBuffer(2 * nf * n), DeviceBuffer(nf * n), fsea.PinnedArray((2 * nf * n,), np.uint8),
+                      fsea.PinnedArray((nf, n), np.uint8)))
+    iqs = [synth_iq(90 + b, 2 * nf * n) for b in range(batches)]
+    got = []
+    for b in range(batches + 2):
+        st, d_in, d_out, h_in, h_out = slots[b % 2]
+        if b >= 2:                                                    # what this slot took two batches ago
+            fsea._check(L.fsea_stream_synchronize(plan._p, st))
+            got.append(h_out.array.copy())
+        if b < batches:
+            h_in.array[:] = iqs[b]
+            fsea._check(L.fsea_copy_to_device_async(0, d_in.ptr, h_in.array.ctypes.data, h_in.array.nbytes, st))
+            plan.exec_device(d_in.ptr, nf, d_out.ptr, stream=st.value)
+            fsea._check(L.fsea_copy_to_host_async(0, h_out.array.ctypes.data, d_out.ptr, nf * n, st))
+    for b in range(batches):
+        parity.check_mode(got[b], iqs[b], n, nf, n, True, fsea.MODE_DB10_U8)
+    for st, d_in, d_out, h_in, h_out in slots:
+        d_in.free()
+        d_out.free()
+        h_in.close()
+        h_out.close()
+        fsea._check(L.fsea_stream_destroy(0, st))
+    plan.close()
+
+
 @pytest.mark.parametrize("n,nf", [(8192, 1500), (4096, 2049), (16384, 700)])
 def test_frame_distribution_does_not_change_a_bit(n, nf):
     """Ticket pools and static interleave are two ways of handing the same frames to the workgroups: the rows are
