@@ -1143,13 +1143,9 @@ struct FftKernel {
 #pragma unroll
             for (int c = 0; c < C1; ++c) ld_c<R1 / 2>(a.tw_def + ((C1 * t1 + c) % Ns1) * (R1 / 2), tw1 + c * (R1 / 2));
         }
-        Raw raw[R0];
-        load_raw(buffer_window(a.in, (size_t)IN_BPS * (RUNS ? fcur : u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
-        if (dyn) {
-            if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
-        }
         // taper window: this lane's weights, and the DC term's spectrum in the band [N/2 - NsL, N/2 + NsL) -- the rows
-        // RL/2 - 1 and RL/2 of the last pass -- on its way to LDS (held in registers it costs spills at 16384 points)
+        // RL/2 - 1 and RL/2 of the last pass -- on its way to LDS (held in registers it costs spills at 16384 points).
+        // Requested in front of unit 0's bytes: they come from L2 and must not queue behind the HBM burst of the launch's start.
         [[maybe_unused]] const rsrc_t win_rs = buffer_window(WIN ? a.win : nullptr, 0, WIN ? (size_t)N * 4u : 0);
         cf wv[WPAIRS];
         cf dcv[WIN ? DC_REGS : 1];
@@ -1160,6 +1156,11 @@ struct FftKernel {
                 const int e = tid + i * Cfg::WG;
                 dcv[i] = a.win_dc[e < 2 * NsL ? e : 2 * NsL - 1];  // clamped, as the table block above
             }
+        }
+        Raw raw[R0];
+        load_raw(buffer_window(a.in, (size_t)IN_BPS * (RUNS ? fcur : u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+        if (dyn) {
+            if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
         }
 
         // The small twiddle block (middle-pass tables + HI/LO factors, a few KiB) goes to LDS, and
