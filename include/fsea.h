@@ -163,7 +163,8 @@ int fsea_plan_set_unit_distribution(fsea_plan *plan, int policy);
  * is current.  Asynchronous with respect to the host.
  * A plan may be launched from several host threads and on any number of streams; launches on
  * one stream run in order, launches on different streams may overlap (up to 64 long launches in flight at a time;
- * a 65th waits for the oldest).  The calls leave the caller's current HIP device unchanged.
+ * a 65th waits for the oldest -- inside the call, holding the plan's slot table, so that other threads launching
+ * the same plan wait with it).  The calls leave the caller's current HIP device unchanged.
  * The call enqueues one kernel; a long launch of the multi-wave sizes (4096 points and up, frames handed out by the
  * ticket pools) additionally records an event behind it, by which its counter slot is recycled.  While the stream is
  * being captured into a hipGraph nothing but the kernel is enqueued
