@@ -433,7 +433,7 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
     if ((kind == fsea::K_U8_MAG || kind == fsea::K_U8_MAG_WIN) && e->fn[half_kind] && !tiles &&
         2 * (size_t)p->hop == (size_t)p->n && n_frames >= 2 && !p->no_half_overlap) {
         const size_t wgs = (size_t)p->num_cu * (size_t)(p->occ[half_kind] > 0 ? p->occ[half_kind] : 1);
-        size_t run = n_frames / wgs;  // frames per run: long enough to reuse most halves, short enough that every workgroup gets some
+        size_t run = (n_frames + wgs - 1) / wgs;  // frames per run: long enough to reuse most halves, short enough that every workgroup gets some
         if (run > (size_t)p->half_run_max) run = (size_t)p->half_run_max;
         if (run < 1) run = 1;
         a.run_len = (uint32_t)run;

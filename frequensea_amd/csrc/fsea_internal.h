@@ -93,7 +93,7 @@ struct fsea_plan {
     // FSEA_UNITS_AUTO: launches with at most FSEA_STATIC_UNITS_PER_WG units per workgroup use the static interleave,
     // longer ones the ticket pools; fsea_plan_set_unit_distribution pins one of the two
     int units_policy = FSEA_UNITS_AUTO;
-    int half_run_max = 16;         // frames per run of the half-overlap kernels at most (FSEA_HALF_RUN_MAX at plan creation; measured 2 .. 32: 8 and 16 equal in rate, 16 fetches 1.064x the distinct bytes where 8 fetches 1.127x, profiles/r04_stft_run_length.txt)
+    int half_run_max = 32;         // frames per run of the half-overlap kernels at most (FSEA_HALF_RUN_MAX at plan creation; 8, 16 and 32 equal in rate, fetch 1.127x / 1.064x / 1.033x the distinct bytes: profiles/r04_stft_run_length.txt)
     bool no_half_overlap = false;  // FSEA_NO_HALF_OVERLAP=1 at plan creation: hop == N/2 runs the ordinary kernel (A/B measurements)
     // staging for the host-buffer entry points
     std::mutex mu;
