@@ -29,6 +29,22 @@ def test_fsea_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_window_fill_and_window_tables_without_a_gpu():
+    """fsea_window_fill is host arithmetic (callable without a device): the periodic cosine-sum tapers are scipy's and the
+    oracle's; a plan-less fsea_plan_set_window fails with FSEA_EINVAL, it does not crash."""
+    from scipy.signal import get_window
+    from oracle import oracle as O
+    L = fsea.hip_lib()
+    for name in ("hann", "hamming", "blackman", "blackmanharris", "flattop"):
+        for n in (32, 1000, 8192):
+            w = fsea.window(name, n)
+            assert w.dtype == np.float32 and np.max(np.abs(w - get_window(name, n))) <= 1e-7, name
+            assert np.array_equal(w, O.window(name, n).astype(np.float32)), name
+    assert np.array_equal(fsea.window("rect", 100), np.ones(100, np.float32))
+    assert L.fsea_window_fill(99, 8, np.zeros(8, np.float32).ctypes.data) == -1          # unknown kind: FSEA_EINVAL
+    assert L.fsea_plan_set_window(None, None) == -1 and L.fsea_plan_window_form(None) == 0
+
+
 def test_tuning_library_is_a_superset_and_the_product_has_no_variants():
     """include/fsea_tune.h lives in libfsea_hip_tune.so only: the product library registers one kernel
     set per size and exports no variant / trace / timing entry point."""
