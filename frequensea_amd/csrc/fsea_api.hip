@@ -112,6 +112,16 @@ size_t mode_elem_bytes(int mode) {
 
 namespace {
 
+// the windowed twin of a u8 kind (a plan with a taper window; fsea_plan_set_window)
+int windowed_kind(int kind) {
+    switch (kind) {
+    case fsea::K_U8_MAG: return fsea::K_U8_MAG_WIN;
+    case fsea::K_U8_DB5: return fsea::K_U8_DB5_WIN;
+    case fsea::K_U8_DB10: return fsea::K_U8_DB10_WIN;
+    default: return fsea::K_U8_WIN;
+    }
+}
+
 // which __global__ entry point serves (input kind, epilogue mode, byte convention)
 int pick_kind(int in_kind, int mode, int flip) {
     if (in_kind == fsea::IN_F32) return fsea::K_F32;
@@ -223,7 +233,10 @@ std::string pow2_kernel_name(const fsea_plan *p) {
     const fsea::KernelEntry *e = p->entry;
     const bool windowed = p->window_form != 0;
     int k = pick_kind(fsea::IN_U8, p->mode, 1);
-    if (windowed) k = (k == fsea::K_U8_MAG) ? fsea::K_U8_MAG_WIN : fsea::K_U8_WIN;
+    if (windowed) {
+        k = windowed_kind(k);
+        if (!e->fn[k]) k = fsea::K_U8_WIN;
+    }
     if (!e->fn[k]) k = fsea::K_U8;
     const int half = windowed ? fsea::K_U8_MAG_HALF_WIN : fsea::K_U8_MAG_HALF;
     if ((k == fsea::K_U8_MAG || k == fsea::K_U8_MAG_WIN) && e->fn[half] && 2 * (size_t)p->hop == (size_t)p->n && !p->no_half_overlap) {
@@ -385,7 +398,8 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
             return fail(FSEA_EINVAL, "the plan has a taper window: the frequency-shifted and the f64-input entry points take "
                                      "none (fsea_plan_set_window(plan, NULL) removes it)");
         }
-        kind = (flip && mode == FSEA_MODE_MAG_F32) ? fsea::K_U8_MAG_WIN : fsea::K_U8_WIN;
+        kind = windowed_kind(kind);
+        if (!e->fn[kind]) kind = fsea::K_U8_WIN;
     }
     // tuning variants carry the u8 MAG and run-time-mode kernels only: their pixel modes run the latter
     if (!e->fn[kind] && (kind == fsea::K_U8_DB5 || kind == fsea::K_U8_DB10)) kind = fsea::K_U8;
@@ -762,8 +776,8 @@ int fsea_plan_set_window(fsea_plan *p, const float *w) {
 int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned *block, size_t *lds_bytes) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
     int k = pick_kind(fsea::IN_U8, p->mode, 1);
-    if (p->window_form) k = (k == fsea::K_U8_MAG) ? fsea::K_U8_MAG_WIN : fsea::K_U8_WIN;
-    if (!p->entry->fn[k]) k = fsea::K_U8;
+    if (p->window_form) k = windowed_kind(k);
+    if (!p->entry->fn[k]) k = p->window_form ? fsea::K_U8_WIN : fsea::K_U8;
     if (grid) *grid = grid_for(p, p->entry, p->occ[k], n_frames);
     if (block) *block = (unsigned)p->entry->wg;
     if (lds_bytes) *lds_bytes = p->entry->lds_bytes;

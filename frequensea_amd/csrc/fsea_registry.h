@@ -16,10 +16,10 @@ namespace fsea {
 // K_F32 takes f32-complex input (the NUT_BUFFER_F64 branch).
 // K_U8_MAG_HALF: the MAG kernel for 50 %-overlapped frames (hop == N/2) of the sizes with one frame per workgroup (8192,
 // 16384): runs of consecutive frames per workgroup, every sample loaded once (FftKernel<..., RUNS = true>).
-// K_U8_MAG_WIN, K_U8_WIN, K_U8_MAG_HALF_WIN: K_U8_MAG, K_U8 and K_U8_MAG_HALF with the taper window fused into pass 0's
-// conversion (FftKernel<..., WIN>; fsea_plan_set_window) -- what a plan with a window launches.
+// K_U8_MAG_WIN, K_U8_WIN, K_U8_MAG_HALF_WIN, K_U8_DB5_WIN, K_U8_DB10_WIN: the u8 kernels with the taper window fused into
+// pass 0 (FftKernel<..., WIN>; fsea_plan_set_window) -- what a plan with a window launches.
 enum : int { K_U8_MAG = 0, K_U8_DB5 = 1, K_U8_DB10 = 2, K_U8 = 3, K_U8_ROT = 4, K_F32 = 5, K_U8_MAG_HALF = 6,
-             K_U8_MAG_WIN = 7, K_U8_WIN = 8, K_U8_MAG_HALF_WIN = 9, K_COUNT = 10 };
+             K_U8_MAG_WIN = 7, K_U8_WIN = 8, K_U8_MAG_HALF_WIN = 9, K_U8_DB5_WIN = 10, K_U8_DB10_WIN = 11, K_COUNT = 12 };
 
 struct KernelEntry {
     int n;                 // transform size
@@ -150,21 +150,29 @@ struct KernelEntry {
     }
 #define FSEA_REGISTER_HALF(NAME) if (n < cap) out[n++] = NAME##_entry_half();
 
-// The windowed kernels of a configuration defined above: NAME_u8_mag_win, NAME_u8_win (and NAME_u8_mag_half_win with
-// HALF = 1).  WMODE: FftKernel's WIN (1 = weights fetched per frame, 2 = register-resident).  FSEA_REGISTER_WIN /
+// The windowed kernels of a configuration defined above: NAME_u8_mag_win, NAME_u8_db5_win, NAME_u8_db10_win (epilogue and
+// byte convention fixed at compile time, as their un-windowed twins), NAME_u8_win (and NAME_u8_mag_half_win with HALF = 1).  WMODE: FftKernel's WIN (1 = weights fetched per frame, 2 = register-resident).  FSEA_REGISTER_WIN /
 // FSEA_REGISTER_HALF_WIN register the entry with them.
 #define FSEA_DEFINE_WINDOWED(NAME, WMODE)                                                             \
     FSEA_KERNEL_FN_(NAME, _u8_mag_win, fsea::IN_U8, fsea::MODE_MAG, false, false, WMODE)              \
+    FSEA_KERNEL_FN_(NAME, _u8_db5_win, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX, false, false, WMODE)     \
+    FSEA_KERNEL_FN_(NAME, _u8_db10_win, fsea::IN_U8, fsea::MODE_DB10_U8, false, false, WMODE)         \
     FSEA_KERNEL_FN_(NAME, _u8_win, fsea::IN_U8, -1, false, false, WMODE)                              \
     static void NAME##_launch_win(int kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {   \
         const dim3 g(grid), b(NAME##_cfg::WG);                                                        \
         if (kind == fsea::K_U8_MAG_WIN) hipLaunchKernelGGL(NAME##_u8_mag_win, g, b, 0, s, a);         \
+        else if (kind == fsea::K_U8_DB5_WIN) hipLaunchKernelGGL(NAME##_u8_db5_win, g, b, 0, s, a);    \
+        else if (kind == fsea::K_U8_DB10_WIN) hipLaunchKernelGGL(NAME##_u8_db10_win, g, b, 0, s, a);  \
         else hipLaunchKernelGGL(NAME##_u8_win, g, b, 0, s, a);                                        \
     }                                                                                                 \
     static void NAME##_add_win(fsea::KernelEntry &e) {                                                \
         e.fn[fsea::K_U8_MAG_WIN] = reinterpret_cast<const void *>(&NAME##_u8_mag_win);                \
+        e.fn[fsea::K_U8_DB5_WIN] = reinterpret_cast<const void *>(&NAME##_u8_db5_win);                \
+        e.fn[fsea::K_U8_DB10_WIN] = reinterpret_cast<const void *>(&NAME##_u8_db10_win);              \
         e.fn[fsea::K_U8_WIN] = reinterpret_cast<const void *>(&NAME##_u8_win);                        \
         e.name[fsea::K_U8_MAG_WIN] = #NAME "_u8_mag_win";                                             \
+        e.name[fsea::K_U8_DB5_WIN] = #NAME "_u8_db5_win";                                             \
+        e.name[fsea::K_U8_DB10_WIN] = #NAME "_u8_db10_win";                                           \
         e.name[fsea::K_U8_WIN] = #NAME "_u8_win";                                                     \
         e.launch_win = &NAME##_launch_win;                                                            \
     }

@@ -110,7 +110,7 @@ static inline int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsi
         else run_grid<Cfg, fsea::IN_U8, -1>(a, grid);
         return 0;
     } else
-    if (!g_window.empty()) {  // windowed kernels: K_U8_MAG_WIN (compile-time MAG), K_U8_WIN, K_U8_MAG_HALF_WIN
+    if (!g_window.empty()) {  // windowed kernels: K_U8_MAG_WIN / K_U8_DB5_WIN / K_U8_DB10_WIN (compile-time mode), K_U8_WIN, K_U8_MAG_HALF_WIN
         if constexpr ((Cfg::OPT & (64 | 1048576 | 8388608)) == 0 && Cfg::TWR) {
             if ((int)g_window.size() != Cfg::N || (in_kind != fsea::IN_U8 && in_kind != 3)) return -5;
             if (in_kind == 3) {
@@ -121,6 +121,12 @@ static inline int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsi
             } else if (mode_t == fsea::MODE_MAG) {
                 if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, false, 1>(a, grid);
                 else run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, false, 2>(a, grid);
+            } else if (mode_t == fsea::MODE_DB5_U8_DCFIX) {
+                if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX, false, false, 1>(a, grid);
+                else run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX, false, false, 2>(a, grid);
+            } else if (mode_t == fsea::MODE_DB10_U8) {
+                if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB10_U8, false, false, 1>(a, grid);
+                else run_grid<Cfg, fsea::IN_U8, fsea::MODE_DB10_U8, false, false, 2>(a, grid);
             } else {
                 if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, -1, false, false, 1>(a, grid);
                 else run_grid<Cfg, fsea::IN_U8, -1, false, false, 2>(a, grid);

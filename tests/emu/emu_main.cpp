@@ -94,8 +94,7 @@ extern "C" int emu_fft_variant(int n, const char *variant, int in_kind, int spec
     a.trace = nullptr;
     // the compile-time-mode kernels (MAG, DB5, DB10) serve raw int8 input (flip)
     const bool has_fixed = mode == fsea::MODE_MAG || mode == fsea::MODE_DB5_U8_DCFIX || mode == fsea::MODE_DB10_U8;
-    int mt = (specialised && has_fixed && in_kind == fsea::IN_U8 && flip) ? mode : -1;
-    if (!g_window.empty() && mt != fsea::MODE_MAG) mt = -1;  // the windowed kernels: compile-time MAG, or run-time mode
+    const int mt = (specialised && has_fixed && in_kind == fsea::IN_U8 && flip) ? mode : -1;
     const std::string v = variant ? variant : "";
     // the per-(size, mode) product configurations (fsea_configs.h)
     if (n == 256 && v == "rows") return dispatch<fsea::FftCfg<FSEA_CFG_256_ROWS>>(in_kind, mt, a, grid);

@@ -287,6 +287,9 @@ def test_windowed_run_time_mode_kernel(n, mode):
         w = _taper(wname, n)
         got = emu_rows(iq, n, nf, flip=flip, mode=mode, window=w, window_mode=1 + (mode & 1), window_form=form)
         parity.check_mode_windowed(got, iq, n, nf, n, flip, mode, w)
+        if mode in (1, 2) and flip:     # the compile-time windowed pixel kernel and the run-time-mode one: the same pixels
+            rt = emu_rows(iq, n, nf, flip=flip, mode=mode, window=w, window_mode=1 + (mode & 1), window_form=form, specialised=False)
+            assert np.array_equal(got, rt)
 
 
 @pytest.mark.parametrize("n", [64, 512, 2048, 8192])

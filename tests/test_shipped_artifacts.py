@@ -14,7 +14,7 @@ from tests.conftest import ROOT
 LIB = os.path.join(ROOT, "frequensea_amd", "libfsea_hip.so")
 SIZES = (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384)
 KINDS = ("u8_mag", "u8_db5", "u8_db10", "u8", "u8_rot", "f32")
-WIN_KINDS = ("u8_mag_win", "u8_win")
+WIN_KINDS = ("u8_mag_win", "u8_db5_win", "u8_db10_win", "u8_win")
 ALT_CONFIGS = ("256rows", "512px", "1024rt")
 
 
