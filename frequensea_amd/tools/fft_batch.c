@@ -15,8 +15,10 @@
  * gate, transform and download of capture k + 1 are queued while capture k is still draining -- the streaming shape of
  * the reference's receive callback (c/fft-batch.c:54-102: a transfer in, a row out) at the granularity of a capture.
  *
- * usage: fsea-fft-batch [--broad] [--rows H] [--fft N] [--skip K] [--out DIR] [--device D] [--timing]
+ * usage: fsea-fft-batch [--broad] [--rows H] [--fft N] [--skip K] [--out DIR] [--device D] [--timing] [--window NAME]
  *                       FREQ_MHZ=capture.raw [FREQ_MHZ=capture.raw ...]
+ *   --window  hann | hamming | blackman | blackmanharris | flattop: a taper beside the reference's (-1)^n, fused into the
+ *             kernel (fsea_plan_set_window; the reference's tools are rectangular, c/fft-batch.c:65-66 -- the default)
  *   --timing  print, at the end, the seconds each of the three stages was busy and the wall time of the loop
  */
 #include <math.h>
@@ -34,6 +36,22 @@
 static void die(const char *what) {
     fprintf(stderr, "fsea-fft-batch: %s: %s\n", what, fsea_last_error_string());
     exit(EXIT_FAILURE);
+}
+
+/* --window NAME: the periodic cosine-sum taper of that name on the plan (include/fsea.h: fsea_window_fill) */
+static int set_named_window(fsea_plan *plan, const char *name, int n) {
+    static const char *names[] = {"rect", "hann", "hamming", "blackman", "blackmanharris", "flattop"};
+    for (int k = 0; k < 6; k++) {
+        if (strcmp(name, names[k]) != 0) continue;
+        float *w = (float *)malloc(sizeof(float) * (size_t)n);
+        if (!w) return -1;
+        int rc = fsea_window_fill(k, n, w);
+        if (rc == 0 && k != 0) rc = fsea_plan_set_window(plan, w);
+        free(w);
+        return rc;
+    }
+    fprintf(stderr, "fsea-fft-batch: unknown window '%s' (hann, hamming, blackman, blackmanharris, flattop)\n", name);
+    return -1;
 }
 
 typedef struct {
@@ -77,7 +95,7 @@ static int load_capture(void *vctx, int item, uint8_t *packed, int *rows_out) {
 
 int main(int argc, char **argv) {
     int broad = 0, rows_wanted = -1, fft_size = -1, skip = 10, device = 0, timing = 0;
-    const char *out_dir = ".";
+    const char *out_dir = ".", *window = NULL;
     int first_capture = argc;
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--broad") == 0) broad = 1;
@@ -87,11 +105,12 @@ int main(int argc, char **argv) {
         else if (strcmp(argv[i], "--out") == 0 && i + 1 < argc) out_dir = argv[++i];
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = atoi(argv[++i]);
         else if (strcmp(argv[i], "--timing") == 0) timing = 1;
+        else if (strcmp(argv[i], "--window") == 0 && i + 1 < argc) window = argv[++i];
         else { first_capture = i; break; }
     }
     if (first_capture >= argc) {
         fprintf(stderr, "usage: fsea-fft-batch [--broad] [--rows H] [--fft N] [--skip K] [--out DIR] "
-                        "[--device D] [--timing] FREQ_MHZ=capture.raw ...\n");
+                        "[--device D] [--timing] [--window NAME] FREQ_MHZ=capture.raw ...\n");
         return EXIT_FAILURE;
     }
     if (fft_size < 0) fft_size = broad ? 256 : 1024;          /* FFT_SIZE */
@@ -102,6 +121,7 @@ int main(int argc, char **argv) {
     if (fsea_plan_create(&plan, fft_size, fft_size, broad ? FSEA_MODE_DB5_U8_DCFIX : FSEA_MODE_DB10_U8, device) != 0) {
         die("fsea_plan_create");
     }
+    if (window && set_named_window(plan, window, fft_size) != 0) die("--window");
     /* two GPU slots: stream + device buffers each; capture k uses slot (number of captures sent to the GPU so far) % 2 */
     typedef struct {
         void *stream, *d_iq, *d_px;

@@ -50,6 +50,7 @@ typedef struct {
     /* shared, read-only */
     int broad, rows_wanted, fft_size, skip, chunk, write_tiles, n_members, n_captures;
     const char *out_dir;
+    const char *window; /* --window NAME: a taper on every member's plan (fsea_plan_set_window), or NULL = rectangular */
     const capture *captures;
     uint32_t width_step, image_width;
     fsea_comm *comm;
@@ -184,6 +185,17 @@ static void *member_main(void *argp) {
     g_writers[me] = &writer;
     CHECK(fsea_plan_create(&plan, n, n, cfg->broad ? FSEA_MODE_DB5_U8_DCFIX : FSEA_MODE_DB10_U8, device) == 0,
           "member %d: fsea_plan_create", me);
+    if (cfg->window) {
+        static const char *names[] = {"rect", "hann", "hamming", "blackman", "blackmanharris", "flattop"};
+        int kind = -1;
+        for (int k = 0; k < 6; k++) {
+            if (strcmp(cfg->window, names[k]) == 0) kind = k;
+        }
+        CHECK(kind >= 0, "unknown window '%s' (hann, hamming, blackman, blackmanharris, flattop)", cfg->window);
+        float *w = (float *)malloc(sizeof(float) * (size_t)n);
+        CHECK(w && fsea_window_fill(kind, n, w) == 0 && (kind == 0 || fsea_plan_set_window(plan, w) == 0), "member %d: --window", me);
+        free(w);
+    }
     CHECK(fsea_comm_stream_create(device, &stream) == 0 && fsea_comm_stream_create(device, &stream2) == 0, "member %d: stream", me);
     CHECK(fsea_device_alloc(device, (size_t)rows * row_in, &d_iq2[0]) == 0 &&
           fsea_device_alloc(device, (size_t)rows * row_in, &d_iq2[1]) == 0, "member %d: alloc", me);
@@ -300,6 +312,7 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--broad") == 0) cfg.broad = 1;
         else if (strcmp(argv[i], "--no-tiles") == 0) cfg.write_tiles = 0;
+        else if (strcmp(argv[i], "--window") == 0 && i + 1 < argc) cfg.window = argv[++i];
         else if (strcmp(argv[i], "--rows") == 0 && i + 1 < argc) cfg.rows_wanted = atoi(argv[++i]);
         else if (strcmp(argv[i], "--fft") == 0 && i + 1 < argc) cfg.fft_size = atoi(argv[++i]);
         else if (strcmp(argv[i], "--skip") == 0 && i + 1 < argc) cfg.skip = atoi(argv[++i]);
@@ -316,7 +329,7 @@ int main(int argc, char **argv) {
     }
     if (first_capture >= argc || cfg.chunk <= 0) {
         fprintf(stderr, "usage: fsea-fft-sweep [--broad] [--devices LIST] [--rows H] [--fft N] [--skip K] [--step MHZ] "
-                        "[--chunk T] [--out DIR] [--no-tiles] FREQ_MHZ=capture.raw ...\n");
+                        "[--chunk T] [--out DIR] [--no-tiles] [--window NAME] FREQ_MHZ=capture.raw ...\n");
         return EXIT_FAILURE;
     }
     if (cfg.fft_size < 0) cfg.fft_size = cfg.broad ? 256 : 1024;        /* FFT_SIZE */

@@ -179,3 +179,38 @@ def test_multi_member_narrow_sweep_with_overlap(tmp_path):
     for k, f in enumerate(freqs):
         O.composite_max(want, np.ascontiguousarray(_png(tmp_path / ("fft-%.4f.png" % f))), k * step)
     assert np.array_equal(_png(tmp_path / "fft-stitched-1802.0000-1808.0000.png"), want)
+
+
+def test_windowed_sweep_tools(tmp_path):
+    """fsea-fft-batch --window hann and fsea-fft-sweep --window hann: tiles equal the oracle's windowed pixel rows
+    (x[j] = (-1)^j w[j] u8[j] / 256 in front of c/fft-batch.c's pixel loop), the sweep's stitched image equals the
+    max-composite of the batch tool's tiles; an unknown window name is refused."""
+    n, rows, skip = 1024, 40, 10
+    freqs = [1802.0, 1804.0, 1806.0]
+    caps = [_capture(tmp_path / ("w%d.raw" % i), 80 + i, rows + skip) for i in range(3)]
+    pairs = ["%.1f=%s" % (f, tmp_path / ("w%d.raw" % i)) for i, f in enumerate(freqs)]
+    (tmp_path / "batch").mkdir()
+    (tmp_path / "sweep").mkdir()
+    subprocess.run([os.path.join(BIN, "fsea-fft-batch"), "--rows", str(rows), "--window", "hann", "--out", str(tmp_path / "batch")] + pairs,
+                   capture_output=True, text=True, check=True)
+    w = O.window("hann", n).astype(np.float32).astype(np.float64)
+    tiles = []
+    for i, f in enumerate(freqs):
+        got = _png(tmp_path / "batch" / ("fft-%.4f.png" % f))
+        want = np.stack([O.rows_windowed(caps[i][skip + rows - 1 - y, : 2 * n], 1, n, w, mode=O.MODE_DB10_U8)[0] for y in range(rows)])
+        assert got.shape == (rows, n) and _close(got, want)
+        plain = np.stack([O.rows(caps[i][skip + rows - 1 - y, : 2 * n], 1, n, mode=O.MODE_DB10_U8)[0] for y in range(rows)])
+        assert not _close(got, plain)                       # and they are not the rectangular tiles
+        tiles.append(got)
+    subprocess.run([os.path.join(BIN, "fsea-fft-sweep"), "--devices", "0,0", "--rows", str(rows), "--window", "hann", "--no-tiles",
+                    "--out", str(tmp_path / "sweep")] + pairs, capture_output=True, text=True, check=True)
+    import glob
+    img = _png(glob.glob(str(tmp_path / "sweep" / "fft-stitched-*.png"))[0])
+    step = n // 2                                           # 2 MHz steps at 5 Msps: WIDTH_STEP = 1024 / 2 (c/fft-stitch.c:21)
+    want = np.zeros((rows, n + 2 * step), np.uint8)
+    for k, t in enumerate(tiles):
+        O.composite_max(want, np.ascontiguousarray(t), k * step)
+    assert np.array_equal(img, want)
+    r = subprocess.run([os.path.join(BIN, "fsea-fft-batch"), "--rows", str(rows), "--window", "kaiser", "--out", str(tmp_path)] + pairs,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown window" in r.stderr
