@@ -313,6 +313,28 @@ def test_windowed_half_overlap_kernel(n):
     parity.check_mode_windowed(got, iq, n, nf, hop, True, 0, w)
 
 
+def test_windowed_random_geometry_sweep():
+    """Seeded random draws of (size, hop, frame count, mode, flip, grid, taper, weight residency) through the windowed
+    kernels: overlapped, gapped and tiny hops, ragged frame counts, every epilogue, cosine-sum / arbitrary / signed weights."""
+    rng = np.random.default_rng(4026)
+    for _ in range(24):
+        n = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 4096]))
+        hop = int(rng.choice([8, 16, n // 4, n // 2, n, n + 8, 2 * n]))
+        nf = int(rng.integers(1, 30 if n <= 1024 else 6))
+        mode = int(rng.integers(0, 6))
+        flip = bool(rng.integers(0, 2))
+        grid = int(rng.choice([1, 2, 3, 8]))
+        kind = str(rng.choice(["hann", "hamming", "flattop", "random", "ramp"]))
+        w = (np.linspace(-1.0, 1.0, n).astype(np.float32) if kind == "ramp" else _taper(kind, n))
+        iq = synth_iq(int(rng.integers(1 << 30)), 2 * ((nf - 1) * hop + n))
+        got = emu_rows(iq, n, nf, hop=hop, flip=flip, mode=mode, grid=grid, specialised=bool(rng.integers(0, 2)), window=w,
+                       window_mode=int(rng.integers(1, 3)))
+        try:
+            parity.check_mode_windowed(got, iq, n, nf, hop, flip, mode, w)
+        except AssertionError as e:
+            raise AssertionError("n=%d hop=%d nf=%d mode=%d flip=%s grid=%d taper=%s: %s" % (n, hop, nf, mode, flip, grid, kind, e))
+
+
 def test_window_tables_decide_the_form():
     """build_window_tables (fsea_tables.h, through the emulated launch): cosine-sum tapers qualify for the centred form --
     then forcing the offset-binary form gives the same rows within tolerance, not the same bits."""
