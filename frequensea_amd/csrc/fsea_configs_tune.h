@@ -169,3 +169,7 @@
 #define FSEA_CFG_32_T2C 32, 2, 128, 2, 2, 2, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS
 #define FSEA_CFG_64_T2C 64, 2, 128, 2, 2, 16, 4, 1, 1, true, true, 0, fo::STREAMING_PIXELS
 #define FSEA_CFG_64_T2D 64, 2, 128, 2, 2, 4, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+// measurement only (wrong rows): the product configuration with 16 / 32 packed ops per lane-frame left out of the middle pass --
+// what a radix-4 regrouping of the in-register DFTs could save at most, as a rate (profiles/r04_radix4_rejected.txt)
+#define FSEA_CFG_8192_M16 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::DROP_16_OPS, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192_M32 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, fsea::abl::DROP_32_OPS, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS

@@ -209,7 +209,8 @@ __device__ __forceinline__ void dft_regs_tw(cf *x, const cf *tw, float sc0) {
 // general 3-op form (plus = a + w b in two packed FMAs, minus = 2a - plus in one) -- the same
 // 3 R log2 R / 2 packed ops as dft_regs_tw.
 // tw layout: [om^{R/2}] [om^{R/4}] [om^{R/8} W_8^{0,1}] [om^{R/16} W_16^{0..3}] ... (fsea_tables.h).
-template <int R, int HALF, int TS>
+// DROP (measurement only, wrong results; abl::DROP_16_OPS / DROP_32_OPS): the levels with HALF <= DROP leave out the `minus` FMA.
+template <int R, int HALF, int TS, int DROP = 0>
 __device__ __forceinline__ void dft_def_level(cf *y, const cf *tw) {
     if constexpr (HALF < R) {
         constexpr int OFF = HALF / 2, DISTINCT = HALF >= 2 ? HALF / 2 : 1;
@@ -219,7 +220,8 @@ __device__ __forceinline__ void dft_def_level(cf *y, const cf *tw) {
             for (int k = 0; k < DISTINCT; ++k) {
                 cf &a = y[base + k], &b = y[base + k + HALF];
                 const cf plus = pk_cmul_add(b, tw[(OFF + k) * TS], a);
-                b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
+                if constexpr (HALF <= DROP) b = a;          // (no op: the old a, a value of its own, so that nothing downstream folds)
+                else b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
                 a = plus;
             }
             if constexpr (HALF >= 2) {
@@ -227,23 +229,24 @@ __device__ __forceinline__ void dft_def_level(cf *y, const cf *tw) {
                 for (int k = 0; k < DISTINCT; ++k) {
                     cf &a = y[base + DISTINCT + k], &b = y[base + DISTINCT + k + HALF];
                     const cf plus = pk_cmul_add_mi(b, tw[(OFF + k) * TS], a);
-                    b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
+                    if constexpr (HALF <= DROP) b = a;
+                    else b = cf_fma(a, cf{2.0f, 2.0f}, -plus);
                     a = plus;
                 }
             }
         }
-        dft_def_level<R, 2 * HALF, TS>(y, tw);
+        dft_def_level<R, 2 * HALF, TS, DROP>(y, tw);
     }
 }
 
-template <int R, int S, int TS>
+template <int R, int S, int TS, int DROP = 0>
 __device__ __forceinline__ void dft_regs_def(cf *x, const cf *tw) {
     static_assert(R >= 4 && R <= 64 && (R & (R - 1)) == 0, "radix must be 4..64");
     constexpr int BITS = ilog2c(R);
     cf y[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) y[bitrev_c(i, BITS)] = x[i * S];
-    dft_def_level<R, 1, TS>(y, tw);
+    dft_def_level<R, 1, TS, DROP>(y, tw);
 #pragma unroll
     for (int i = 0; i < R; ++i) x[i * S] = y[i];
 }
@@ -809,7 +812,7 @@ struct FftKernel {
                 after_reads();
                 frame_sync();
 #pragma unroll
-                for (int c = 0; c < C; ++c) dft_regs_def<R, C, 1>(v + c, tw_res + c * (R / 2));
+                for (int c = 0; c < C; ++c) dft_regs_def<R, C, 1, (Cfg::ABL & abl::DROP_32_OPS) ? 2 : ((Cfg::ABL & abl::DROP_16_OPS) ? 1 : 0)>(v + c, tw_res + c * (R / 2));
             } else if constexpr (TW_HOIST && (Cfg::Ns(I) % C == 0)) {
                 constexpr int Ns = Cfg::Ns(I);
                 cf w[(R - 1) * C];

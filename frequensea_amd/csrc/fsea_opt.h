@@ -33,6 +33,8 @@ enum : int {
     V2_STATIC = 8, V2_V1_LOADS = 16, V2_NO_EXCHANGE_A = 32,   // V2-schedule ablations
     NO_LOADS = 64,          // the first unit's bytes are reused for every frame
     NO_EPILOGUE_MATH = 128, // no magnitude arithmetic / no logarithm
+    DROP_16_OPS = 256,      // the middle pass leaves out 16 packed ops per lane-frame (the `minus` FMA of its first level), DROP_32_OPS = 512:
+    DROP_32_OPS = 512,      // of its first two levels -- what a radix-4 regrouping could save at most, as a rate (profiles/r04_radix4_rejected.txt)
 };
 }  // namespace abl
 }  // namespace fsea

@@ -16,7 +16,7 @@ fsea.use_tune_library()
 VARIANTS = {
     8192: ["", "cp0", "nd", "st_nt", "ld_nt", "x0", "v2", "v2s", "A", "B", "D", "B2", "D2", "W", "W2", "notwl", "notwr",
            "abl_nostore", "abl_nolds", "abl_noflop", "abl_io", "abl_valu", "abl_noload", "abl_nomag",
-           "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na", "abl_px_nolog"],
+           "abl_io_nt", "abl_nolds_nt", "abl_noflop_nt", "abl_v2l", "abl_v2sl", "abl_v2na", "abl_px_nolog", "abl_m16", "abl_m32"],
     1024: ["", "cp0", "ldst_nt", "x0", "B", "C", "D"],
     4096: ["", "w64", "s2", "nr", "cp0", "st_nt", "t256", "x0", "df", "B", "B3", "C", "D",
            "abl_px_nolog", "abl_px_nost", "abl_px_io"],
