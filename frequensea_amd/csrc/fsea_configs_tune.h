@@ -5,15 +5,13 @@
 #include "fsea_configs.h"
 
 // round-1 configurations of the sizes whose product configuration changed in round 2
-// (OPT 256: +-i butterflies as packed FMAs; no deferred twiddles)
 // packed-add +-i butterflies without the deferred twiddles
 #define FSEA_CFG_8192_ND 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_16384_ND 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::TW_FUSE
 // deferred twiddles on the sizes that did not gain from them
 #define FSEA_CFG_4096_DF 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, fo::DEFER | fo::TW_FUSE | fo::BATCH_READS
 #define FSEA_CFG_2048_DF 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::DEFER | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-// OPT 512 (late ticket wait) and OPT 1024 (static priority for one of the two co-resident workgroups)
-// cache policy of the input loads / output stores (OPT 4096 nt stores, 8192 sc1, 16384 sc0, 32768 nt loads):
+// cache policy of the input loads / output stores (fo::ST_NT nt stores, fo::LD_NT nt loads; the sc0 / sc1 store variants were removed in round 4):
 // "cp0" = default policy for both (the round-2 kernel before the policy was chosen), then the alternatives
 #define FSEA_CFG_8192_CP0 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_8192_STNT 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
@@ -28,7 +26,7 @@
 #define FSEA_CFG_1024_LDSTNT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::TW_FUSE | fo::BATCH_READS
 #define FSEA_CFG_256_CP0 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, 0
 #define FSEA_CFG_256_LDSTNT 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::LD_NT | fo::ST_NT
-// V2 schedule (OPT 64): first exchange inside each wavefront, two barriers per frame; with its
+// V2 schedule (fo::V2): first exchange inside each wavefront, two barriers per frame; with its
 // measurement-only ablations (8: static units + early prefetch, 16: V1 load mapping, wrong results,
 // 32: no first exchange, wrong results)
 #define FSEA_CFG_8192_V2 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::V2 | fo::TW_FUSE | fo::BATCH_READS
@@ -67,7 +65,7 @@
 #define FSEA_CFG_4096_T256 4096, 256, 1, 4, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::TW_FUSE | fo::BATCH_READS
 #define FSEA_CFG_4096_F1 4096, 128, 1, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_4096_B3 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-// lane rotation against LDS read conflicts (OPT 16 = middle pass, 32 = last pass) switched OFF where the product has it:
+// lane rotation against LDS read conflicts (fo::LANE_ROT = middle pass, fo::LANE_ROT_LAST = last pass) switched OFF where the product has it:
 // 4096 without the last-pass rotation, 2048 without the middle-pass rotation (scripts/lds_conflicts.py predicts 2 cycles
 // per ds_read_b128 group; measured SQ_LDS_BANK_CONFLICT 4.3 M / 8.5 M cycles per launch against 0.1 M / 4.3 M with it)
 #define FSEA_CFG_4096_LR 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* "nr": without the last-pass rotation */
@@ -108,12 +106,12 @@
 #define FSEA_CFG_2048_X0 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, 0
 #define FSEA_CFG_1024_X0 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, 0
 // 4096 points as ONE wavefront per frame, 64 lanes x 64 points, no s_barrier (round 3):
-// "w64": 64 x 64, one exchange (FftKernel::run_w64; OPT 1048576), last-pass twiddles deferred and register-resident;
+// "w64": 64 x 64, one exchange (FftKernel::run_w64; fo::W64), last-pass twiddles deferred and register-resident;
 // "s2": 16 x 16 x 16 in the V1 schedule, two exchanges, dwordx2 loads and four adjacent bins per lane in the last pass
 #define FSEA_CFG_4096_W64 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, fo::W64 | fo::LD_NT | fo::ST_NT | fo::BATCH_READS
 #define FSEA_CFG_4096_S2 4096, 64, 1, 1, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_4096_W64B 4096, 64, 1, 1, 2, 64, 64, 1, 1, false, false, 0, fo::PX_BIAS | fo::W64 | fo::LD_NT | fo::ST_NT | fo::BATCH_READS   /* + biased rounding instead of v_trunc */
-// pixel epilogue with v_cvt_pk_u8_f32 (OPT 2097152: v_trunc + convert-and-pack; + 4194304: biased rounding, no v_trunc)
+// pixel epilogue with v_cvt_pk_u8_f32 (fo::PX_PACK: v_trunc + convert-and-pack; + fo::PX_BIAS: biased rounding, no v_trunc)
 // "pk": with the v_trunc (exact truncation); "px0": the round-2 form (cast, clamp, shift/or); the product has both bits
 #define FSEA_CFG_4096_PK 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::PX_PACK | fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_4096_PX0 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::LD_NT | fo::ST_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
@@ -156,9 +154,7 @@
 #define FSEA_CFG_4096_83216 4096, 128, 2, 2, 3, 8, 32, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_8192_163216 8192, 256, 1, 2, 3, 16, 32, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_8192_83232 8192, 256, 1, 2, 3, 8, 32, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-// OPT 8388608: the last butterfly level of the last pass in power form (dft_regs_tw_pw) in the MAG / DB10 / DB5 kernels;
-// "pw" = the product configuration + that bit; the small sizes do not fuse the last pass's twiddles (OPT 8) in the
-// product, which the power form builds on: "f8" = product + OPT 8, "pw" = product + OPT 8 + power form
+// "f8" = the product configuration + fo::TW_FUSE at the small sizes (what round 3's power-form experiment, removed in round 4, built on)
 #define FSEA_CFG_512_F8 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::TW_FUSE
 #define FSEA_CFG_256_F8 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::TW_FUSE
 // 32 / 64 points with two lanes per frame (16 / 32 points per lane): radix orders by pass-0 load width and bins per lane

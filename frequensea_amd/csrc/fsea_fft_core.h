@@ -623,7 +623,7 @@ struct FftKernel {
     // 2048 had had it since round 1).
     template <int ELEM_BYTES>
     static constexpr int st_aux() { return (T * CL * ELEM_BYTES >= 128 && CL * ELEM_BYTES <= 16) ? ST_AUX : (ST_AUX & ~2); }
-    // OPT 32768: the input loads are streaming (nt) as well
+    // opt::LD_NT: the input loads are streaming (nt) as well
     static constexpr int LD_AUX = (Cfg::OPT & opt::LD_NT) ? 2 : 0;
     static constexpr bool DEFER = (Cfg::OPT & opt::DEFER) != 0 && NP == 3;
     static constexpr bool PX_PACK = (Cfg::OPT & opt::PX_PACK) != 0;   // pixel epilogue: v_trunc + v_cvt_pk_u8_f32
@@ -899,9 +899,9 @@ struct FftKernel {
                     // smaller p -- down to log2(0) = -inf, which the conversion saturates -- the pixel
                     // is 0 either way.  Left out: same pixels, one VALU op less per bin.
                     if constexpr (PX_PACK) {
-                        // OPT 2097152: truncation (v_trunc_f32), then v_cvt_pk_u8_f32, which saturates to [0, 255] and
+                        // opt::PX_PACK: truncation (v_trunc_f32), then v_cvt_pk_u8_f32, which saturates to [0, 255] and
                         // drops the byte into place: 2 ops where the cast + clamp + shift/or packing took 2 + ~0.75.
-                        // OPT 4194304 (with it): no v_trunc; the conversion rounds to nearest even, so d is lowered by
+                        // opt::PX_BIAS (with it): no v_trunc; the conversion rounds to nearest even, so d is lowered by
                         // 0.5 - 2^-25 in the FMA that forms it: floor(d) except for d within ~8e-6 above an odd integer
                         // (one pixel in ~2.5e5 one grey level low; the f32 logarithm itself moves more than that).
                         float d;
@@ -1138,7 +1138,7 @@ struct FftKernel {
             const int e = tid + i * Cfg::WG;
             tabv[i] = a.tw_small[e < TAB_COPY ? e : TAB_COPY - 1];  // clamped, not predicated: no branch
         }
-        // deferred middle-pass twiddles (OPT 128): row k = (C1 t + c) % Ns1 of the table, per column
+        // deferred middle-pass twiddles (opt::DEFER): row k = (C1 t + c) % Ns1 of the table, per column
         constexpr int R1 = Cfg::R(1), C1 = Cfg::C(1), Ns1 = Cfg::Ns(1);
         cf tw1[DEFER ? C1 * (R1 / 2) : 1];
         if constexpr (DEFER) {

@@ -5,7 +5,7 @@
 //   run_w64 / pixels_w64   opt::W64: 4096 points as 64 x 64 in one wavefront (profiles/r03_w64_and_pixel_epilogue.txt)
 //   run_v2 / wave_order    opt::V2: first exchange inside each wavefront, two barriers per frame (profiles/r02_tune_v2_schedule.txt)
     // -----------------------------------------------------------------------------------------
-    // W64 schedule (OPT 1048576): N = 64 x 64, one wavefront per frame, 64 points per lane, ONE exchange
+    // W64 schedule (opt::W64): N = 64 x 64, one wavefront per frame, 64 points per lane, ONE exchange
     // through LDS and no s_barrier at all.
     //
     // Sample n = 64 n1 + n2, bin k = k1 + 64 k2.  Pass 0: lane n2 transforms x[64 n1 + n2] over n1 (64 points, constant

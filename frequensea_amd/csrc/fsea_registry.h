@@ -88,7 +88,7 @@ struct KernelEntry {
 
 // Tuning variants (libfsea_hip_tune.so only): the MAG kernel and the run-time-mode kernel.  The pixel modes of such a
 // plan run the run-time-mode kernel; its f32-input and frequency-shifted kinds do not exist (launch() fails with
-// FSEA_EINVAL).  The V2 schedule (OPT 64) always hands its frames out by the ticket pools: fsea_plan_set_unit_distribution
+// FSEA_EINVAL).  The V2 schedule (opt::V2) always hands its frames out by the ticket pools: fsea_plan_set_unit_distribution
 // has no effect on a V2 variant.
 #define FSEA_DEFINE_KERNEL_LITE(NAME, VARIANT, ...)                                                   \
     using NAME##_cfg = fsea::FftCfg<__VA_ARGS__>;                                                     \
