@@ -4,7 +4,6 @@
 
 #include "fsea_configs.h"
 
-// round-1 configurations of the sizes whose product configuration changed in round 2
 // packed-add +-i butterflies without the deferred twiddles
 #define FSEA_CFG_8192_ND 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_16384_ND 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::TW_FUSE
@@ -140,7 +139,7 @@
 #define FSEA_CFG_1024_G 1024, 32, 8, 2, 3, 16, 16, 4, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_1024_H 1024, 32, 8, 2, 3, 8, 8, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_1024_FD 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* f + deferred middle-pass twiddles */
-#define FSEA_CFG_1024_F0 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* f without the middle-pass lane rotation (OPT 16) */
+#define FSEA_CFG_1024_F0 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* f without the middle-pass lane rotation (fo::LANE_ROT) */
 #define FSEA_CFG_1024_FL 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS   /* f without nt loads */
 // Round 3, after 1024 gained from wider pass-0 loads and four bins per lane: the same question at the other sizes
 // (full u8 kernel sets with the product's options; names = the radix order)

@@ -73,7 +73,7 @@ struct fsea_plan {
     hipStream_t stream = nullptr;
     fsea::cf *d_tw = nullptr;      // passes 1..np-1 concatenated
     size_t tw_off[5] = {0, 0, 0, 0, 0};  // passes 0..3, then the HI/LO factor tables (fsea_tables.h)
-    size_t tw_def_off = 0;               // deferred middle-pass table (OPT 128 / V2), 16-byte aligned
+    size_t tw_def_off = 0;               // deferred middle-pass table (fo::DEFER / fo::V2), 16-byte aligned
     int num_cu = 0;
     // Ticket counters of the multi-wave sizes: one slot per stream the plan is launched on.  Launches
     // on one stream run in order and the last workgroup of a launch zeroes its slot, so a stream
