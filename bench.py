@@ -168,12 +168,19 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repea
     if world == 1 and (args.two_stream or not args.no_extra) and workload.startswith("batch"):
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         torch.cuda.synchronize()
-        for k in range(max(8, warmup)):
-            s = k % sets
-            plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=streams[k % 2].cuda_stream)
-        torch.cuda.synchronize()
+        # the same clock pre-warm as the one-stream figure gets, on the two streams: 20 launches from a chip that has
+        # idled through the copies above run at a boost clock the sustained loop never sees (102 M against 91 M frames/s
+        # at 8192 points; scripts/two_stream_lengths.py, profiles/r04_two_stream_lengths.txt)
+        t_pre = time.perf_counter()
+        k = 0
+        while k < max(8, warmup) or time.perf_counter() - t_pre < args.prewarm:
+            for _ in range(64):
+                s = k % sets
+                plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=streams[k % 2].cuda_stream)
+                k += 1
+            torch.cuda.synchronize()
         rates = []
-        for rep in range(max(1, repeats)):
+        for rep in range(max(3, repeats)):
             t2 = time.perf_counter()
             for k in range(steps):
                 s = k % sets
