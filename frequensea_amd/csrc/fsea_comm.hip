@@ -218,6 +218,39 @@ int fsea_comm_gather(fsea_comm *c, int member, const void *d_src, const size_t *
     return 0;
 }
 
+int fsea_comm_selftest_rccl(int device, size_t bytes) {
+    if (bytes == 0) return fail("fsea_comm_selftest_rccl: bytes must be positive");
+    COMM_HIP(hipSetDevice(device));
+    std::vector<unsigned char> host(bytes), back(bytes);
+    for (size_t i = 0; i < bytes; ++i) host[i] = (unsigned char)((i * 2654435761u) >> 13);
+    unsigned char *d_src = nullptr, *d_dst = nullptr;
+    hipStream_t s = nullptr;
+    ncclComm_t comm = nullptr;
+    int rc = 0;
+    auto body = [&]() -> int {
+        COMM_HIP(hipMalloc(reinterpret_cast<void **>(&d_src), bytes));
+        COMM_HIP(hipMalloc(reinterpret_cast<void **>(&d_dst), bytes));
+        COMM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        COMM_HIP(hipMemcpy(d_src, host.data(), bytes, hipMemcpyHostToDevice));
+        COMM_HIP(hipMemset(d_dst, 0, bytes));
+        COMM_NCCL(ncclCommInitAll(&comm, 1, &device));
+        COMM_NCCL(ncclGroupStart());
+        COMM_NCCL(ncclSend(d_src, bytes, ncclUint8, 0, comm, s));
+        COMM_NCCL(ncclRecv(d_dst, bytes, ncclUint8, 0, comm, s));
+        COMM_NCCL(ncclGroupEnd());
+        COMM_HIP(hipStreamSynchronize(s));
+        COMM_HIP(hipMemcpy(back.data(), d_dst, bytes, hipMemcpyDeviceToHost));
+        if (std::memcmp(host.data(), back.data(), bytes) != 0) return fail("RCCL self send/recv of %zu bytes arrived altered", bytes);
+        return 0;
+    };
+    rc = body();
+    if (comm) (void)ncclCommDestroy(comm);
+    if (s) (void)hipStreamDestroy(s);
+    if (d_src) (void)hipFree(d_src);
+    if (d_dst) (void)hipFree(d_dst);
+    return rc;
+}
+
 int fsea_comm_barrier(fsea_comm *c, int member, void *stream) {
     if (!c || member < 0 || member >= c->n) return fail("fsea_comm_barrier: bad arguments");
     COMM_HIP(hipSetDevice(c->devices[member]));

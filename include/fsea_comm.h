@@ -53,6 +53,13 @@ int fsea_comm_gather(fsea_comm *comm, int member, const void *d_src, const size_
  * issued before it are complete on the root and all source buffers may be reused. */
 int fsea_comm_barrier(fsea_comm *comm, int member, void *stream);
 
+/* First-contact check of the RCCL backend on a box with ONE GPU, where fsea_comm_create has nothing to gather over:
+ * a one-rank communicator on `device` (ncclCommInitAll), then the gather's own call pattern -- ncclGroupStart,
+ * ncclSend + ncclRecv of `bytes` bytes of a known pattern with peer 0 (the rank itself), ncclGroupEnd -- on a
+ * non-blocking stream, and a byte-for-byte comparison of what arrived.  0 = RCCL loaded, initialised, moved the bytes
+ * and they are right; non-zero with fsea_comm_last_error() otherwise.  Says nothing about xGMI. */
+int fsea_comm_selftest_rccl(int device, size_t bytes);
+
 const char *fsea_comm_last_error(void);
 
 #ifdef __cplusplus

@@ -67,6 +67,18 @@ PY
 fi
 if [ "$N" -lt 1 ]; then echo "VERDICT: no GPU visible" | tee -a "$LOG"; exit 1; fi
 
+# ---- 0. RCCL by itself, one GPU at a time: a one-rank communicator and the gather's grouped send / recv with itself ----
+d=0
+while [ $d -lt "$N" ]; do
+  run "rccl self-loop on device $d (fsea_comm_selftest_rccl, 64 MiB)" python -c "
+import ctypes, sys
+L = ctypes.CDLL('frequensea_amd/libfsea_rccl.so'); L.fsea_comm_selftest_rccl.argtypes = [ctypes.c_int, ctypes.c_size_t]
+L.fsea_comm_last_error.restype = ctypes.c_char_p
+rc = L.fsea_comm_selftest_rccl($d, 64 << 20)
+print('rc', rc, '' if rc == 0 else L.fsea_comm_last_error().decode()); sys.exit(1 if rc else 0)"
+  d=$((d + 1))
+done
+
 # ---- 1. the C tool over RCCL ------------------------------------------------------------------------------------
 W=${TMPDIR:-/tmp}/fsea_mgc.$$
 CAPS=""

@@ -2,6 +2,7 @@
 against the oracle's restatement of c/fft-batch*.c and c/fft-stitch*.c, PNGs decoded with PIL."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -214,3 +215,42 @@ def test_windowed_sweep_tools(tmp_path):
     r = subprocess.run([os.path.join(BIN, "fsea-fft-batch"), "--rows", str(rows), "--window", "kaiser", "--out", str(tmp_path)] + pairs,
                        capture_output=True, text=True)
     assert r.returncode != 0 and "unknown window" in r.stderr
+
+
+def test_rccl_moves_bytes_on_this_box():
+    """The RCCL backend of libfsea_rccl.so on a box with one GPU: a one-rank communicator and the gather's own grouped
+    ncclSend / ncclRecv with the rank itself as the peer (fsea_comm_selftest_rccl) -- RCCL loads, initialises, runs its
+    kernels on a non-blocking stream and the bytes arrive unchanged.  (With two or more GPUs the sweep tests above run
+    the real gather.)"""
+    import ctypes
+    L = ctypes.CDLL(os.path.join(os.path.dirname(BIN), "libfsea_rccl.so"))
+    L.fsea_comm_selftest_rccl.argtypes = [ctypes.c_int, ctypes.c_size_t]
+    L.fsea_comm_last_error.restype = ctypes.c_char_p
+    for nbytes in (1, 4096, 256 * 4096 + 3, 64 << 20):      # one byte, a tile row, a ragged chunk, 64 MiB
+        rc = L.fsea_comm_selftest_rccl(0, nbytes)
+        assert rc == 0, (nbytes, L.fsea_comm_last_error().decode())
+
+
+def test_torch_nccl_backend_initialises_on_this_box(tmp_path):
+    """bench.py's N > 1 runs use torch.distributed's nccl backend (= RCCL): world size 1 here, the calls the bench makes --
+    init_process_group with a device id, barrier, all_reduce(MAX) of the timing pair, batch_isend_irecv with itself."""
+    code = r"""
+import os, torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dist.barrier()
+t = torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.tolist() == [1.5, 2.5]
+src = torch.arange(1 << 20, dtype=torch.uint8, device="cuda")
+dst = torch.zeros_like(src)
+for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, 0), dist.P2POp(dist.irecv, dst, 0)]):
+    w.wait()
+torch.cuda.synchronize()
+assert torch.equal(src, dst)
+dist.destroy_process_group()
+print("NCCL_OK")
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "NCCL_OK" in res.stdout, res.stderr[-2000:]

@@ -70,7 +70,7 @@ def test_comm_library_exports_every_declared_symbol():
     names = set(re.findall(r"\b(fsea_comm_[a-z0-9_]+)\s*\(", text))
     assert names == {"fsea_comm_create", "fsea_comm_destroy", "fsea_comm_size", "fsea_comm_backend",
                      "fsea_comm_stream_create", "fsea_comm_stream_destroy", "fsea_comm_gather", "fsea_comm_barrier",
-                     "fsea_comm_last_error"}
+                     "fsea_comm_selftest_rccl", "fsea_comm_last_error"}
     for name in names:
         assert hasattr(L, name), name
     import subprocess
