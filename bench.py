@@ -214,14 +214,14 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     lo, hi = sweep.partition(tiles, world, rank)
     plan = fsea.Plan(n, hop=n, mode=fsea.MODE_DB5_U8_DCFIX, device=dev.index)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(4000000 + lo)
     tile_bytes = 2 * rows * n
     samples = (hi - lo) * rows * n
     iq = torch.empty(2 * samples, dtype=torch.int8, device=dev)
-    chunk = 1 << 24
-    for s0 in range(0, 2 * samples, chunk):                     # int8 Gaussian sigma=20, generated on device
-        e0 = min(2 * samples, s0 + chunk)
-        iq[s0:e0] = torch.clamp(torch.round(torch.randn(e0 - s0, generator=gen, device=dev) * 20.0), -128, 127).to(torch.int8)
+    for f in range(lo, hi):                                     # int8 Gaussian sigma=20, generated on device, one seed per
+        gen.manual_seed(4000000 + f)                            # centre frequency (seed = 4e6 + f): the sweep's
+        s0 = (f - lo) * tile_bytes                              # captures, and with them the stitched image, are the same
+        iq[s0:s0 + tile_bytes] = torch.clamp(torch.round(torch.randn(tile_bytes, generator=gen, device=dev) * 20.0),
+                                             -128, 127).to(torch.int8)   # however many ranks share the work
     ingest = args.regime == "ingest"
     host_iq = None
     if ingest:
@@ -237,19 +237,26 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     # under chunk j's drain; the stream that gathers and stitches (`compute`) waits for each chunk where it consumes it
     lanes = [torch.cuda.Stream(), torch.cuda.Stream()] if n_chunks > 1 else None
     issued = [0]
+    step_no = [0]
+    lane_step = [-1, -1]
 
-    def launch_stream(first_of_step_dependency):
+    def launch_stream():
         if lanes is None:
             return compute
-        s = lanes[issued[0] % 2]
-        if issued[0] % n_chunks == 0 and first_of_step_dependency:
-            s.wait_stream(compute)                              # e.g. the zero fill of this step's image
+        k = issued[0] % 2
+        s = lanes[k]
+        if lane_step[k] != step_no[0]:
+            # each lane's FIRST launch of a step waits for `compute`: this step's image (allocated, possibly zero-filled, on
+            # `compute` inside run_sweep before the first chunk is produced) and the previous step's sends of the buffer the
+            # launch is about to overwrite (only the first chunk of a step used to wait)
+            s.wait_stream(compute)
+            lane_step[k] = step_no[0]
         issued[0] += 1
         return s
 
     def make_tiles(a, b):                                       # tiles a..b-1 of the sweep, one launch
         s0, s1 = (a - lo) * tile_bytes, (b - lo) * tile_bytes
-        st = launch_stream(False)
+        st = launch_stream()
         if ingest:
             with torch.cuda.stream(copy_stream):
                 iq[s0:s1].copy_(host_iq[s0:s1], non_blocking=True)
@@ -263,7 +270,7 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
 
     def write_tiles(image, a, b):                               # rank 0's own tiles, straight into the stitched image
         s0 = (a - lo) * tile_bytes
-        st = launch_stream(True)
+        st = launch_stream()
         if ingest:
             with torch.cuda.stream(copy_stream):
                 iq[s0:(b - lo) * tile_bytes].copy_(host_iq[s0:(b - lo) * tile_bytes], non_blocking=True)
@@ -286,6 +293,7 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
                                  device=dev.index, stream=stream)
 
     def step():
+        step_no[0] += 1
         return sweep.run_sweep(tiles, (rows, n), make_tiles, composite, dist=dist, torch=torch, device=dev,
                                composite_stack=composite_stack, n_chunks=n_chunks,
                                write_tiles=None if args.no_fused_stitch else write_tiles)
@@ -368,6 +376,43 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
                           device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kernel_ms = float(tt[0]), float(tt[1])
+    # What arrived against what was sent: every rank recomputes its own tiles in ONE plain launch (no chunks, no tiled
+    # stores) and takes their checksum; rank 0 takes the checksum of the same tiles as they sit in the stitched image after
+    # the chunked gather of the last timed step.  A chunk at the wrong offset, a byte lost on the wire or a lane racing its
+    # consumer shows up here, in the driver's own record.
+    plan.exec_device(iq.data_ptr(), (hi - lo) * rows, px.data_ptr(), flip=True, stream=stream)
+    torch.cuda.synchronize()
+    sums = gather_objects(dist, world, (lo, hi, sweep.checksum(torch, px)))
+    gathered_ok, gathered_sum = None, None
+    if rank == 0:
+        arrived = [sweep.checksum(torch, sweep.tiles_of_image(img, a, b, n)) for a, b, _ in sums]
+        gathered_ok = all(x == y for x, (_, _, y) in zip(arrived, sums))
+        gathered_sum = "%016x" % sweep.checksum(torch, img)     # of the whole stitched image: the same at every world size
+        if not gathered_ok:
+            bad = [r for r, (x, (_, _, y)) in enumerate(zip(arrived, sums)) if x != y]
+            raise SystemExit("bench broad: the gathered tiles of rank(s) %s differ from what those ranks computed" % bad)
+    # The gather by itself: the same chunked exchange with the tiles already computed (no FFT in the region), so that the
+    # record holds what one peer -> root link carried per second.  Under gloo it is host staging + TCP, and says so.
+    gather_only_ms = None
+    if dist is not None:
+        def produce_ready(a, b):
+            return None if rank == 0 else px[a - lo: b - lo]
+
+        def place(a, b, stack):
+            img[:, a * n: b * n].view(rows, b - a, n).copy_(stack.permute(1, 0, 2))
+        for it in range(2 + 5):
+            if it == 2:
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+            sweep.gather_chunked(tiles, (rows, n), torch.uint8, produce_ready, place, dist=dist, torch=torch, device=dev,
+                                 n_chunks=n_chunks)
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - tg) / 5], dtype=torch.float64,
+                          device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        gather_only_ms = 1e3 * float(tt[0])
     check = None
     if rank == 0:
         head = iq[: 2 * n * 2].cpu().numpy().view(np.uint8)
@@ -407,9 +452,25 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
         "ms_per_step_kernel_events": kernel_ms, "host_issue_ms_per_step": host_issue_ms,
         "roofline_frac_by_step_time": alg / (wall / steps) / 1e9 / HBM_PEAK_GBPS if world == 1 else None,
         "ms_per_step_two_streams": two_stream_ms, "timed_regions": max(1, repeats),
+        "gathered_checksum_ok": gathered_ok, "gathered_checksum": gathered_sum,
     }
+    if gather_only_ms is not None:
+        peer_bytes = max((b - a) * rows * n for a, b in (sweep.partition(tiles, world, r) for r in range(1, world)))
+        root_bytes = (tiles - (sweep.partition(tiles, world, 0)[1])) * rows * n
+        line.update({"gather_only_ms": gather_only_ms, "gather_bytes_per_peer": peer_bytes,
+                     "gather_gbps_per_link": peer_bytes / (gather_only_ms * 1e-3) / 1e9,
+                     "gather_gbps_into_root": root_bytes / (gather_only_ms * 1e-3) / 1e9})
     plan.close()
     return line
+
+
+def gather_objects(dist, world, obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (a small control-plane collective; [obj] without a job)."""
+    if dist is None:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
 
 
 def stream_block(torch, dev, block, block_samples):
@@ -454,8 +515,17 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
     lanes = [torch.cuda.Stream(), torch.cuda.Stream()] if n_chunks > 1 else None   # consecutive chunks alternate (run_broad)
     issued = [0]
 
+    step_no = [0]
+    lane_step = [-1, -1]
+
     def make_rows(a, b):
-        st = compute if lanes is None else lanes[issued[0] % 2]
+        st = compute
+        if lanes is not None:
+            k = issued[0] % 2
+            st = lanes[k]
+            if lane_step[k] != step_no[0]:                      # first launch of a step on this lane: behind the previous
+                st.wait_stream(compute)                         # step's sends of the rows it is about to overwrite
+                lane_step[k] = step_no[0]
         issued[0] += 1
         plan.exec_device(iq.data_ptr() + 2 * (a * hop - s_lo), b - a, rows.data_ptr() + 4 * n * (a - f_lo), flip=True,
                          stream=st.cuda_stream)
@@ -464,6 +534,7 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
         return rows[a - f_lo: b - f_lo]
 
     def step():
+        step_no[0] += 1
         return sweep.run_stft(total_frames, n, make_rows, out, dist=dist, torch=torch, device=dev, n_chunks=n_chunks)
 
     for _ in range(max(warmup, 1)):
@@ -491,6 +562,20 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
         tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, kernel_ms = float(tt[0]), float(tt[1])
+    # what arrived against what was sent (run_broad): every rank's rows, recomputed in one launch into a buffer of their own
+    fresh = torch.empty((f_hi - f_lo, n), dtype=torch.float32, device=dev)
+    plan.exec_device(iq.data_ptr(), f_hi - f_lo, fresh.data_ptr(), flip=True, stream=stream)
+    torch.cuda.synchronize()
+    sums = gather_objects(dist, world, (f_lo, f_hi, sweep.checksum(torch, fresh)))
+    del fresh
+    gathered_ok, gathered_sum = None, None
+    if rank == 0:
+        arrived = [sweep.checksum(torch, out[a:b]) for a, b, _ in sums]
+        gathered_ok = all(x == y for x, (_, _, y) in zip(arrived, sums))
+        gathered_sum = "%016x" % sweep.checksum(torch, out)     # of all rows of the stream: the same at every world size
+        if not gathered_ok:
+            bad = [r for r, (x, (_, _, y)) in enumerate(zip(arrived, sums)) if x != y]
+            raise SystemExit("bench stft stream: the gathered rows of rank(s) %s differ from what those ranks computed" % bad)
     rel = None
     if rank == 0:                                               # rows 0, 1 and the last one against numpy
         head = stream_block(torch, dev, 0, block_samples)[: 2 * (hop + n)].cpu().numpy().view(np.uint8)
@@ -516,6 +601,7 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup):
                      "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": plan.kernel_name, "avg_launch_ms": kernel_ms, "algorithmic_bytes_per_launch": alg},
         "parity_rel_l2_first_rows": rel,
+        "gathered_checksum_ok": gathered_ok, "gathered_checksum": gathered_sum,
     }
     plan.close()
     return line
@@ -738,6 +824,85 @@ def cpu_baseline(n, hop, cores, budget_s, nrf_stream=False):
     return out
 
 
+def multi_gpu_leg(args, rank, world, dist, torch, stage):
+    """The two BASELINE workloads that have a real exchange step, in the form north_star scales them, run by the SAME
+    command line the driver uses for its scaling record (`bench.py --gpus N`), after the headline's timed steps:
+
+      config 4  the fft-batch-broad sweep (c/fft-batch-broad.c:176-206: the centre-frequency loop; c/fft-stitch-broad.c:62-87:
+                the stitch) -- centre frequencies sharded over the ranks, u8 tiles gathered to rank 0 over RCCL chunk by
+                chunk under the next chunk's FFT, stitched image on rank 0 -- in both regimes of SURVEY 8(e): captures
+                resident in HBM, and captures ingested over every rank's own PCIe link inside the step;
+      config 5  one 16384-point 50 %-overlap stream, frame ranges with a redundantly read halo, f32 rows gathered to rank 0.
+
+    Both are strong-scaling figures (the job is fixed, a step is the whole job including gather and stitch) and live in
+    `extra`; `value` stays the headline's.  `stage` (a one-element list) names what is running, for the watchdog's message.
+    Returns (flat keys for `extra`, {name: full line} for `extra.multi_gpu_lines`)."""
+    import copy
+    backend = dist.get_backend() if dist is not None else None
+    flat = {"gather_backend": backend if backend else "none (one rank, nothing to gather)", "gather_chunks": None}
+    lines = {}
+    stage[0] = "communicator census"
+    # what the communicator itself reports: a SUM of ones over its ranks, on the device under nccl (an RCCL all-reduce)
+    if dist is not None:
+        one = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        flat["rccl_world"] = int(one[0])
+        flat["torch_world_size"] = dist.get_world_size()
+    else:
+        flat["rccl_world"] = 1
+        flat["torch_world_size"] = 1
+    if backend == "nccl":
+        try:
+            flat["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            flat["rccl_version"] = None
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    ident = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or torch.cuda.current_device())
+    devs = gather_objects(dist, world, (rank, torch.cuda.current_device(), ident))
+    flat["rank_devices"] = ["rank %d: device %d (%s)" % d for d in devs]
+    flat["distinct_gpus"] = len(set(d[2] for d in devs))
+    R = EXTRA_REGIONS if world == 1 else 3
+    regimes = {}
+    for regime in ("resident", "ingest"):
+        stage[0] = "broad sweep, %s regime" % regime
+        a2 = copy.copy(args)
+        a2.regime = regime
+        br = run_broad(a2, rank, world, dist, torch, 20 if world == 1 else 10, 3, repeats=R)
+        lines["broad_" + regime] = br
+        flat["broad_sweep_ms_" + regime] = br["ms_per_step"]
+        flat["broad_sweep_frames_per_sec_" + regime] = br["value"]
+        flat["broad_sweep_%s_gathered_checksum_ok" % regime] = br["gathered_checksum_ok"]
+        flat["broad_sweep_%s_gathered_checksum" % regime] = br["gathered_checksum"]
+        regimes["broad_sweep_ms_" + regime] = br["config"]["regime"]
+        flat["gather_chunks"] = br["config"]["gather_chunks"]
+        if "gather_only_ms" in br and regime == "resident":
+            flat.update({k: br[k] for k in ("gather_only_ms", "gather_bytes_per_peer", "gather_gbps_per_link", "gather_gbps_into_root")})
+    if "gather_only_ms" not in flat:
+        flat.update({"gather_only_ms": None, "gather_bytes_per_peer": 0, "gather_gbps_per_link": None, "gather_gbps_into_root": None})
+    stage[0] = "stft stream"
+    a2 = copy.copy(args)
+    a2.window = None
+    st = run_stft_stream(a2, rank, world, dist, torch, 5, 2)
+    lines["stft_stream"] = st
+    flat["stft_stream_ms"] = st["ms_per_step"]
+    flat["stft_stream_frames_per_sec"] = st["value"]
+    flat["stft_stream_gathered_checksum_ok"] = st["gathered_checksum_ok"]
+    flat["stft_stream_gathered_checksum"] = st["gathered_checksum"]
+    regimes["stft_stream_ms"] = st["config"]["regime"]
+    flat["regime"] = regimes
+    flat["multi_gpu_note"] = ("strong scaling: the sweep (512 x 256 x 4096-pt -> one stitched u8 image on rank 0) and the stream "
+                              "(%d x 16384-pt rows on rank 0) are fixed jobs, a step is the whole job including gather and stitch; "
+                              "compare *_ms across the driver's N = 1, 2, 4, 8 lines; *_gathered_checksum is of the whole stitched image / of all rows "
+                              "on rank 0 and must be the same at every N (the captures are seeded per centre frequency / per stream block).  gather_gbps_per_link = the largest peer's "
+                              "bytes / the gather alone (tiles precomputed, all peers sending at once)" % args.stream_frames)
+    flat["multi_gpu_lines"] = {k: {"ms_per_step": v["ms_per_step"], "frames_per_sec": v["value"], "steps": v["steps"],
+                                   "kernel_ms_largest_shard": v["roofline"]["avg_launch_ms"],
+                                   "kernel_roofline_frac": v["roofline"]["frac"], "kernel": v["roofline"]["kernel"]}
+                               for k, v in lines.items()}
+    stage[0] = "done"
+    return flat, lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -761,6 +926,10 @@ def main():
     ap.add_argument("--two-stream", action="store_true",
                     help="(default since round 3, kept for old command lines) the steps issued alternately on two streams, in `extra`")
     ap.add_argument("--cpu-budget", type=float, default=16.0, help="core-seconds for the CPU sample")
+    ap.add_argument("--no-multi-gpu-leg", action="store_true",
+                    help="skip the sharded sweep + stream (RCCL gather) that follow the headline steps in `extra`")
+    ap.add_argument("--multi-gpu-timeout", type=float, default=240.0,
+                    help="seconds the multi-GPU leg may take before the line is printed without it (extra.multi_gpu_error)")
     args = ap.parse_args()
 
     # Kernel arguments in device memory instead of host-coherent memory: the first s_load of a launch
@@ -870,6 +1039,11 @@ def main():
         if not rel <= 1e-6:
             raise SystemExit("bench: GPU rows differ from the numpy guard (rel %.3e)" % rel)
 
+    br = None
+    if world > 1 and args.workload == "batch8192x4096" and not args.window and not args.no_multi_gpu_leg:
+        # The driver's N > 1 command line: after the headline's steps, the workloads north_star actually scales over a node
+        mg_flat, mg_lines = guarded_multi_gpu_leg(args, rank, world, dist, torch, line)
+        line["extra"] = mg_flat
     if world == 1 and not args.no_extra and args.workload == "batch8192x4096" and not args.window:
         # Everything in `extra` is informational.  Each figure: the same clock pre-warm as the headline, then the MEDIAN of
         # EXTRA_REGIONS timed regions of K' steps (HIP events per region) -- not one sample of a 20-step region.
@@ -912,7 +1086,10 @@ def main():
                               "hann_n8192_kernel": h8["kernel"],
                               "hann_n8192_over_rect": r8["kernel_ms"] / h8["kernel_ms"]})
         line["extra"].update(energy_per_frame(torch))
-        br = run_broad(args, rank, world, dist, torch, 20, 3, repeats=R)
+        mg_flat, mg_lines = guarded_multi_gpu_leg(args, rank, world, dist, torch, line)
+        line["extra"].update(mg_flat)
+        br = mg_lines.get("broad_resident")
+    if world == 1 and not args.no_extra and args.workload == "batch8192x4096" and not args.window and br is not None:
         line["extra"].update({"broad_sweep_1gpu_frames_per_sec": br["value"], "broad_sweep_1gpu_ms": br["ms_per_step"],
                               "broad_sweep_1gpu_kernel_ms": br["ms_per_step_kernel_events"],
                               "broad_sweep_1gpu_host_issue_ms": br["host_issue_ms_per_step"],
@@ -923,6 +1100,7 @@ def main():
                                                   "kernel_ms = the tiled FFT launch by HIP events; the difference is the first "
                                                   "submission + last synchronise of a 20-step region (a few tens of us) spread "
                                                   "over its steps, plus Python's per-step issue time where that exceeds the kernel"})
+    if world == 1 and not args.no_extra and args.workload == "batch8192x4096" and not args.window:
         line["extra"].update(host_path_rate(n, frames))
         line["extra"].update(nrf_stream_rate())
         # what bounds the headline kernel from above on THIS box, same launch shape and buffer rotation: its I/O skeleton
@@ -950,10 +1128,84 @@ def main():
         line["cpu_baseline"] = cb
         line["gpu_over_cpu_all_cores"] = value / cb["value"]
 
-    if rank == 0:
-        print(json.dumps(line))
+    emit_line(line, rank)
     if dist is not None:
+        if line.get("extra", {}).get("multi_gpu_error") or _LEG_FAILED[0]:
+            # a rank left the leg by an exception: its peers may sit in a collective it never joined; the line is out, so
+            # this rank leaves without the process group's closing handshake (which could wait for them)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
+
+
+_EMIT_LOCK = None
+_EMITTED = [False]
+_LEG_FAILED = [False]
+
+
+def emit_line(line, rank):
+    """Rank 0 prints THE one JSON line, once -- whether main() got to its end or the multi-GPU leg's watchdog fired first."""
+    global _EMIT_LOCK
+    import threading
+    if _EMIT_LOCK is None:
+        _EMIT_LOCK = threading.Lock()
+    with _EMIT_LOCK:
+        if _EMITTED[0]:
+            return
+        _EMITTED[0] = True
+        if rank == 0:
+            print(json.dumps(line))
+            sys.stdout.flush()
+
+
+def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
+    """multi_gpu_leg() under a guard: whatever happens in it -- an exception on this rank, a peer that died, a collective that
+    never completes on a fabric this code has not met yet -- the headline's line (already measured; `value` is not touched
+    by anything here) is printed, with the failure named in extra.multi_gpu_error.  A watchdog thread covers the case that
+    cannot raise: after --multi-gpu-timeout seconds rank 0 prints the line as it stands and every rank leaves."""
+    import threading
+    import traceback
+    stage = ["starting"]
+
+    def on_timeout():
+        msg = "the multi-GPU leg did not finish within %.0f s (stage: %s); line printed without it" % (args.multi_gpu_timeout, stage[0])
+        line.setdefault("extra", {})["multi_gpu_error"] = msg
+        print("bench.py rank %d: %s" % (rank, msg), file=sys.stderr)
+        emit_line(line, rank)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    dog = threading.Timer(args.multi_gpu_timeout, on_timeout)
+    dog.daemon = True
+    dog.start()
+    flat, lines = {}, {}
+    try:
+        flat, lines = multi_gpu_leg(args, rank, world, dist, torch, stage)
+        flat["multi_gpu_error"] = None
+    except BaseException as e:                                   # SystemExit from the leg's own checks included
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        _LEG_FAILED[0] = True
+        flat = {"multi_gpu_error": "rank %d, stage %s: %s: %s" % (rank, stage[0], type(e).__name__, e)}
+        print("bench.py rank %d: multi-GPU leg failed in stage %s\n%s" % (rank, stage[0], traceback.format_exc()), file=sys.stderr)
+    dog.cancel()
+    if dist is not None and not _LEG_FAILED[0]:
+        # did every rank get through?  (a rank that failed is not here: a short watchdog then ends the wait)
+        args.multi_gpu_timeout, stage[0] = 45.0, "closing census (a peer left the leg early: see its stderr)"
+        dog = threading.Timer(45.0, on_timeout)
+        dog.daemon = True
+        dog.start()
+        try:
+            oks = gather_objects(dist, world, flat.get("multi_gpu_error"))
+            bad = [(r, m) for r, m in enumerate(oks) if m]
+            if bad:
+                flat["multi_gpu_error"] = "; ".join("rank %d: %s" % b for b in bad)
+        except BaseException as e:
+            _LEG_FAILED[0] = True
+            flat["multi_gpu_error"] = "closing census: %s: %s" % (type(e).__name__, e)
+    dog.cancel()
+    return flat, lines
 
 
 if __name__ == "__main__":

@@ -75,10 +75,15 @@ def gather_chunked(n_items, item_shape, dtype, produce, consume, dist=None, torc
             assert tuple(t.shape) == (b - a,) + tuple(item_shape) and t.dtype == dtype
             if staged:
                 t = t.cpu()
-            pending.append((dist.isend(t, dst=0), t))      # the tensor stays alive until its send has completed
+            # a one-op batch, not a bare isend: ProcessGroupNCCL routes batched point-to-point operations through the job's
+            # communicator and bare ones through a two-rank communicator of their own -- the root's receives are batched
+            # (one ncclGroup per chunk index), so the members' sends must be too, or the two sides sit on different communicators
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, t, 0)])
+            pending.append((reqs, t))                      # the tensor stays alive until its send has completed
             sent += t.numel() * t.element_size()
-        for req, _ in pending:
-            req.wait()
+        for reqs, _ in pending:
+            for req in reqs:
+                req.wait()
         return sent
     # rank 0: receives of chunk index j from all peers are one group; its own chunk j is computed meanwhile
     depth = max(len(r) for r in ranges) if ranges else 0
@@ -172,6 +177,32 @@ def run_stft(n_frames, n, make_rows, out_rows, dist=None, torch=None, device=Non
 
     return gather_chunked(n_frames, (n,), dtype, make_rows, consume, dist=dist, torch=torch, device=device,
                           n_chunks=n_chunks)
+
+
+def checksum(torch, t):
+    """Position-sensitive 64-bit checksum of a tensor's bytes (sum of (2 i + 1) * word_i over its little-endian 64-bit
+    words, modulo 2^64; a tail shorter than a word is zero-padded), computed where the tensor lives.  bench.py's
+    multi-GPU leg compares the checksum every member takes of its own rows before they travel with the one rank 0
+    takes of what arrived, so that a chunk placed at the wrong offset or a byte lost on the wire shows up in the
+    driver's record."""
+    b = t.contiguous().view(torch.uint8).reshape(-1)
+    pad = (-b.numel()) % 8
+    if pad:
+        b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)])
+    w = b.view(torch.int64)
+    total = 0
+    piece = 1 << 22
+    for s in range(0, w.numel(), piece):
+        e = min(w.numel(), s + piece)
+        idx = torch.arange(s, e, dtype=torch.int64, device=w.device)
+        total += int((w[s:e] * (2 * idx + 1)).sum())          # int64 arithmetic wraps on the CPU and on the GPU alike
+    return total & 0xFFFFFFFFFFFFFFFF
+
+
+def tiles_of_image(image, a, b, n):
+    """Tiles a..b-1 of a stitched image of side-by-side tiles (WIDTH_STEP = N) as the [b - a, H, N] stack their owner holds."""
+    h = image.shape[0]
+    return image[:, a * n: b * n].reshape(h, b - a, n).permute(1, 0, 2).contiguous()
 
 
 def numpy_tiles_to_torch(torch, tiles, device):

@@ -533,6 +533,57 @@ double orc_time_mag_rows_mt(const uint8_t *iq, size_t n_frames, int n, size_t ho
     return t1 - t0;
 }
 
+/* ---- whole rows on several cores (the parity tests' full-size comparisons) ---- */
+
+typedef struct {
+    const uint8_t *iq;
+    size_t f0, f1, hop, row_bytes;
+    int n, flip, mode, rc;
+    const double *window;
+    uint8_t *out;
+} orc_rows_job;
+
+static void *orc_rows_worker(void *arg) {
+    orc_rows_job *job = (orc_rows_job *)arg;
+    /* the single-threaded function itself on this thread's frames: the rows cannot differ from orc_rows' */
+    job->rc = orc_rows_windowed(job->iq + 2 * job->f0 * job->hop, job->f1 - job->f0, job->n, job->hop, job->flip,
+                                job->mode, job->window, job->out + job->f0 * job->row_bytes);
+    return NULL;
+}
+
+int orc_rows_mt(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                const double *window, int n_threads, void *out) {
+    if (mode < 0 || mode > 5) return -2;
+    if (n_threads < 1) n_threads = 1;
+    if ((size_t)n_threads > n_frames) n_threads = n_frames ? (int)n_frames : 1;
+    const size_t row_bytes = (mode == 1 || mode == 2) ? (size_t)n
+                             : (mode == 3)            ? sizeof(double) * 2 * (size_t)n
+                                                      : sizeof(double) * (size_t)n;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    orc_rows_job *jobs = (orc_rows_job *)calloc((size_t)n_threads, sizeof(orc_rows_job));
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].iq = iq;
+        jobs[t].f0 = n_frames * (size_t)t / (size_t)n_threads;
+        jobs[t].f1 = n_frames * (size_t)(t + 1) / (size_t)n_threads;
+        jobs[t].hop = hop;
+        jobs[t].row_bytes = row_bytes;
+        jobs[t].n = n;
+        jobs[t].flip = flip;
+        jobs[t].mode = mode;
+        jobs[t].window = window;
+        jobs[t].out = (uint8_t *)out;
+        pthread_create(&th[t], NULL, orc_rows_worker, &jobs[t]);
+    }
+    int rc = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].rc != 0) rc = jobs[t].rc;
+    }
+    free(th);
+    free(jobs);
+    return rc;
+}
+
 /* ---- cpu_baseline through an FFTW3-API library (dlopen) ------------------- */
 
 #include <dlfcn.h>

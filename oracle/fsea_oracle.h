@@ -112,6 +112,13 @@ int orc_rows_windowed(const uint8_t *iq, size_t n_frames, int n, size_t hop, int
  * sets of scipy.signal.windows (tests/test_oracle.py checks them against scipy.signal.get_window). */
 int orc_window_fill(int kind, int n, double *w);
 
+/* orc_rows / orc_rows_windowed (window == NULL: the reference's rectangular frames) with the frames cut into n_threads
+ * contiguous ranges, one pthread each running the single-threaded function on its range -- the same rows bit for bit, in
+ * the time the GPU tier can afford for EVERY row of a BASELINE.json configuration (4096 x 8192, 32768 x 1024,
+ * 131072 x 4096 pixels, 32767 x 16384).  Restates src/nrf.c:598-631 per frame like orc_rows. */
+int orc_rows_mt(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                const double *window, int n_threads, void *out);
+
 /* nrf_freq_shifter_process on interleaved IQ (src/nrf.c:843-866): for every sample,
  *   out_i = vi*cos - vq*sin + 0.5,  out_q = vi*sin + vq*cos + 0.5,
  * then (cos, sin) advance by the angle 2*pi*freq_offset/sample_rate through the reference's own

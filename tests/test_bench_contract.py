@@ -29,6 +29,81 @@ def test_bench_and_smoke_refuse_to_run_without_a_gpu():
     assert r.returncode != 0 and "__SMOKE_OK__" not in r.stdout
 
 
+GUARD_SCRIPT = r"""
+import argparse, json, sys, time
+sys.path.insert(0, %r)
+import bench
+mode = sys.argv[1]
+def leg(args, rank, world, dist, torch, stage):
+    stage[0] = "broad sweep, resident regime"
+    if mode == "raise":
+        raise SystemExit("bench broad: the gathered tiles of rank(s) [1] differ")
+    if mode == "hang":
+        time.sleep(60)
+    return {"rccl_world": 1}, {}
+bench.multi_gpu_leg = leg
+args = argparse.Namespace(multi_gpu_timeout=1.0)
+line = {"metric": "fft_frames_per_sec_n8192", "value": 123.0}
+flat, lines = bench.guarded_multi_gpu_leg(args, 0, 1, None, None, line)
+line["extra"] = flat
+bench.emit_line(line, 0)
+bench.emit_line(line, 0)          # a second call prints nothing
+"""
+
+
+@pytest.mark.parametrize("mode", ["ok", "raise", "hang"])
+def test_the_multi_gpu_leg_can_fail_or_hang_without_costing_the_line(mode):
+    """`value` is measured before the multi-GPU leg and nothing in the leg may cost the driver its line: an exception lands in
+    extra.multi_gpu_error, a hang ends at the watchdog, which prints the line as it stands -- one line, exit code 0."""
+    r = subprocess.run([sys.executable, "-c", GUARD_SCRIPT % ROOT, mode], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 123.0
+    err = d["extra"]["multi_gpu_error"]
+    if mode == "ok":
+        assert err is None and d["extra"]["rccl_world"] == 1
+    elif mode == "raise":
+        assert "stage broad sweep, resident regime" in err and "differ" in err
+    else:
+        assert "did not finish within 1 s" in err and "broad sweep, resident regime" in err
+
+
+MULTI_GPU_KEYS = ("broad_sweep_ms_resident", "broad_sweep_ms_ingest", "stft_stream_ms", "regime", "gather_chunks",
+                  "gather_backend", "rccl_world", "broad_sweep_resident_gathered_checksum_ok",
+                  "broad_sweep_ingest_gathered_checksum_ok", "stft_stream_gathered_checksum_ok", "gather_gbps_per_link",
+                  "multi_gpu_error", "distinct_gpus", "rank_devices")
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_runs_the_sharded_sweep_and_stream_with_a_gather():
+    """The driver's own N > 1 command line (`python -m torch.distributed.run ... bench.py --gpus 2 ...`), two ranks sharing
+    this box's one GPU over gloo (RCCL refuses two ranks on one device): after the headline's steps the line must carry
+    the sharded config-4 sweep in both regimes and the config-5 stream, gathered to rank 0, with the checksums of what
+    arrived against what the members computed."""
+    env = dict(os.environ, FSEA_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+                        "--warmup", "5", "--stream-frames", "4095"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["metric"] == "fft_frames_per_sec_n8192"
+    ex = d["extra"]
+    for key in MULTI_GPU_KEYS:
+        assert key in ex, key
+    assert ex["multi_gpu_error"] is None
+    assert ex["gather_backend"] == "gloo" and ex["rccl_world"] == 2 and ex["gather_chunks"] == 8
+    assert ex["broad_sweep_resident_gathered_checksum_ok"] is True and ex["broad_sweep_ingest_gathered_checksum_ok"] is True
+    assert ex["stft_stream_gathered_checksum_ok"] is True
+    assert ex["broad_sweep_ms_resident"] > 0 and ex["broad_sweep_ms_ingest"] > 0 and ex["stft_stream_ms"] > 0
+    assert ex["gather_gbps_per_link"] > 0 and ex["gather_bytes_per_peer"] == 256 * 256 * 4096
+    assert "resident" in ex["regime"]["broad_sweep_ms_resident"] and "ingest" in ex["regime"]["broad_sweep_ms_ingest"]
+    # the sweep's image does not depend on how many ranks made it: same checksum as the one-rank line's (next test)
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
@@ -65,6 +140,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert 0.5 < roof["kernel_over_io_skeleton"] < 1.0 and 0.5 < roof["kernel_over_copy"] < 1.0
     ex = d["extra"]
     assert ex["host_path_frames_per_sec_n8192"] > 0
+    # the multi-GPU leg's keys at N = 1: the first point of the driver's scaling curve
+    for key in MULTI_GPU_KEYS:
+        assert key in ex, key
+    assert ex["multi_gpu_error"] is None and ex["rccl_world"] == 1 and ex["gather_gbps_per_link"] is None
+    assert ex["broad_sweep_resident_gathered_checksum_ok"] is True and ex["stft_stream_gathered_checksum_ok"] is True
+    assert abs(ex["broad_sweep_ms_resident"] - ex["broad_sweep_1gpu_ms"]) < 1e-12 and ex["broad_sweep_ms_ingest"] > ex["broad_sweep_ms_resident"]
     # independent batches on two streams: one launch's drain under the next one's ramp; beside `value`, never in it
     assert 0.9 * d["value"] < ex["two_stream_frames_per_sec_n8192"] < 1.3 * d["value_events"]
     assert 0.1 < ex["stft16384_roofline_frac"] < 1.0 and 0.1 < ex["broad_sweep_roofline_frac"] < 1.0

@@ -216,3 +216,63 @@ def test_single_process_sweep_matches():
 
     img = sweep.run_sweep(TILES, (H, N), make_tiles, composite, dist=None, torch=torch, device="cpu", width_step=STEP)
     assert np.array_equal(img.numpy(), _expected())
+
+
+# ---- bench.py's multi-GPU leg: what arrived against what was sent -------------------------------------------------
+def test_checksum_sees_position_and_value():
+    a = torch.arange(1000, dtype=torch.uint8).reshape(10, 100)
+    base = sweep.checksum(torch, a)
+    assert base == sweep.checksum(torch, a.clone()) and 0 <= base < 2 ** 64
+    b = a.clone()
+    b[3, 7] ^= 1
+    assert sweep.checksum(torch, b) != base                     # one bit
+    c = a.clone()
+    c[0], c[1] = a[1], a[0]
+    assert sweep.checksum(torch, c) != base                     # two rows swapped: a plain sum would not notice
+    assert sweep.checksum(torch, a.reshape(-1)[:999]) != base   # a tail shorter than a word is zero-padded, not dropped
+    f = torch.linspace(0, 1, 4099, dtype=torch.float32)
+    assert sweep.checksum(torch, f) == sweep.checksum(torch, f.view(torch.int32))      # bytes, whatever the dtype
+    # layout independence the leg relies on: tiles side by side in an image == the owner's [cnt, H, N] stack
+    stack = torch.randint(0, 256, (3, 4, 8), dtype=torch.uint8)
+    image = torch.zeros((4, 5 * 8), dtype=torch.uint8)
+    image[:, 8:32].view(4, 3, 8).copy_(stack.permute(1, 0, 2))
+    assert torch.equal(sweep.tiles_of_image(image, 1, 4, 8), stack)
+    assert sweep.checksum(torch, sweep.tiles_of_image(image, 1, 4, 8)) == sweep.checksum(torch, stack)
+
+
+def _leg_worker(rank, world, port, out_path, corrupt):
+    """The verification of bench.py's multi-GPU leg, with the oracle as the source: every rank's checksum of its own tiles
+    (all_gather_object) against rank 0's checksum of the same tiles as they sit in the gathered image."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sweep.partition(TILES, world, rank)
+        mine = torch.from_numpy(np.stack([_tile(f) for f in range(lo, hi)]))
+
+        def make_tiles(a, b):
+            t = mine[a - lo: b - lo].clone()
+            if corrupt and rank == world - 1 and a == lo:
+                t[0, 0, 0] ^= 0x40                               # a byte damaged on its way
+            return t
+
+        def write_tiles(image, a, b):
+            image[:, a * N: b * N].view(H, b - a, N).copy_(mine[a - lo: b - lo].permute(1, 0, 2))
+
+        img = sweep.run_sweep(TILES, (H, N), make_tiles, None, dist=dist, torch=torch, device="cpu", n_chunks=2,
+                              write_tiles=write_tiles)
+        sums = [None] * world
+        dist.all_gather_object(sums, (lo, hi, sweep.checksum(torch, mine)))
+        if rank == 0:
+            arrived = [sweep.checksum(torch, sweep.tiles_of_image(img, a, b, N)) for a, b, _ in sums]
+            np.save(out_path, np.array([x == y for x, (_, _, y) in zip(arrived, sums)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,corrupt", [(2, False), (3, False), (3, True)])
+def test_gathered_checksums_match_what_the_members_computed(tmp_path, world, corrupt):
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_leg_worker, args=(world, _free_port(), out, corrupt), nprocs=world, join=True)
+    ok = np.load(out)
+    assert ok.tolist() == [True] * (world - 1) + [not corrupt]

@@ -1,7 +1,7 @@
 """GPU tier (-m gpu): the HIP path, called through the C ABI of libfsea_hip.so and through the
 reference-shaped nrf_fft API of libfsea_nrf.so, against the f64 oracle, the committed golden
 vectors from the reference's recorded captures, and -- at BASELINE.json's full sizes -- through
-size-independent properties (Parseval, tone position, sampled rows).  Tolerances: tests/parity.py."""
+size-independent properties (Parseval, tone position) and every row against the threaded oracle.  Tolerances: tests/parity.py."""
 import ctypes
 import os
 
@@ -629,8 +629,8 @@ def test_invalid_arguments_are_reported():
 
 @pytest.mark.parametrize("n,nf", [(8192, 4096), (1024, 32768), (4096, 8192)])
 def test_full_size_properties(n, nf):
-    """BASELINE.json sizes: Parseval on every row, tone position, and 24 sampled rows vs the
-    oracle (the oracle would need minutes for all of them)."""
+    """BASELINE.json sizes: Parseval on every row, tone position, and EVERY row against the oracle (its frames sharded
+    over the host's cores, oracle.rows_mt: the single-threaded rows bit for bit)."""
     iq = synth_iq(3, 2 * nf * n)                      # seed 3 = SURVEY 8(d) config C3
     d_in = DeviceBuffer(iq.nbytes).upload(iq)
     d_out = DeviceBuffer(nf * n * 4)
@@ -651,10 +651,11 @@ def test_full_size_properties(n, nf):
     plan.exec_device(d_in.ptr, nf, d_out.ptr)
     plan.synchronize()
     got = d_out.download(np.float32, (nf, n))
-    rows = np.unique(np.r_[0, 1, nf - 1, np.random.default_rng(n).integers(0, nf, 21)])
-    for f in rows:
-        want = O.rows(iq[2 * f * n: 2 * (f + 1) * n], 1, n)[0]
-        parity.check_float(got[f], want)
+    want = O.rows_mt(iq, nf, n)
+    slab = max(1, (1 << 22) // n)                       # the tolerance is per row set: slabs keep the L2 figure local
+    for f0 in range(0, nf, slab):
+        parity.check_float(got[f0:f0 + slab], want[f0:f0 + slab])
+    del want
     # MAG == MAG_NODC everywhere except the patched bin: bit for bit where the two modes run the same configuration of the
     # size, within the rounding of two radix orders where they do not (1024 points: frequensea_amd/csrc/fsea_configs.h)
     keep = np.ones(n, bool)
@@ -1049,20 +1050,20 @@ def test_batches_beyond_4_gib(n):
 
 
 def test_pixel_modes_at_full_size():
-    """BASELINE batch (8192 points x 4096 frames) through the u8 dB epilogues: sampled rows against the
-    oracle (exact on >= 99.9 % of pixels, +-1 elsewhere) and the DC-fix column of the broad mode."""
+    """BASELINE batch (8192 points x 4096 frames) through the u8 dB epilogues: every row against the
+    oracle (exact on >= 99.9 % of pixels, +-1 elsewhere, per slab of 64 rows) and the DC-fix column of the broad mode."""
     n, nf = 8192, 4096
     iq = synth_iq(3, 2 * nf * n)
     d_in = DeviceBuffer(iq.nbytes).upload(iq)
     d_out = DeviceBuffer(nf * n)
-    rows = np.unique(np.r_[0, nf - 1, np.random.default_rng(11).integers(0, nf, 14)])
     for mode in (fsea.MODE_DB10_U8, fsea.MODE_DB5_U8_DCFIX):
         plan = fsea.Plan(n, mode=mode)
         plan.exec_device(d_in.ptr, nf, d_out.ptr)
         plan.synchronize()
         px = d_out.download(np.uint8, (nf, n))
-        for f in rows:
-            parity.check_u8(px[f], O.rows(iq[2 * f * n: 2 * (f + 1) * n], 1, n, mode=parity.ORACLE_MODE[mode])[0])
+        want = O.rows_mt(iq, nf, n, mode=parity.ORACLE_MODE[mode])
+        for f0 in range(0, nf, 64):
+            parity.check_u8(px[f0:f0 + 64], want[f0:f0 + 64])
         if mode == fsea.MODE_DB5_U8_DCFIX:
             assert np.array_equal(px[:, n // 2], px[:, n // 2 - 1])        # c/fft-batch-broad.c:113-115
         plan.close()
@@ -1155,11 +1156,30 @@ def _rows_from_device(d_out, frames, n, dtype):
     return out
 
 
+def _compare_every_row_of_a_periodic_stream(d_out, nf, n, period, want, dtype, slab=512):
+    """Rows 0..nf-1 on the device against `want` (one period of oracle rows: row f must equal want[f % period]),
+    slab by slab so that neither side needs the whole array in host memory twice."""
+    L = fsea.hip_lib()
+    item = np.dtype(dtype).itemsize
+    buf = np.empty((slab, n), dtype)
+    for f0 in range(0, nf, slab):
+        cnt = min(slab, nf - f0)
+        fsea._check(L.fsea_copy_to_host(0, buf.ctypes.data, ctypes.c_void_p(d_out.ptr.value + f0 * n * item), cnt * n * item))
+        idx = (f0 + np.arange(cnt)) % period
+        ref = want[idx]
+        if np.dtype(dtype) == np.uint8:
+            parity.check_u8(buf[:cnt], ref)
+        else:
+            parity.check_float(buf[:cnt], ref)
+
+
 def test_config_c5_stft_16384_at_full_size():
     """BASELINE config 5 at its full size: 2^28 samples as one stream, 16384-point frames every 8192
-    samples (32767 frames, 2 GiB of f32 rows).  Sampled rows against the oracle, Parseval on them, and
-    the overlap itself: frames f and f + 1 share half their input, which a per-frame phase ramp makes
-    visible in the complex spectrum of a pure tone (checked through the oracle rows instead)."""
+    samples (32767 frames, 2 GiB of f32 rows).  EVERY row against the oracle -- the stream repeats with a period of 4096
+    frames, so the oracle transforms one period (the frame across the seam included) on the host's cores and all eight
+    repetitions are compared with it -- Parseval on sampled rows, and the overlap itself: frames f and f + 1 share half
+    their input, which a per-frame phase ramp makes visible in the complex spectrum of a pure tone (checked through the
+    oracle rows instead)."""
     n, hop = 16384, 8192
     chunk = synth_iq(5, 1 << 26)                              # 32 Mi samples, repeated 8 times
     n_chunks = 8
@@ -1178,10 +1198,11 @@ def test_config_c5_stft_16384_at_full_size():
     for row, f in zip(got, frames):
         s0 = (f * hop) % (chunk.size // 2)
         iq = stream[2 * s0: 2 * (s0 + n)]
-        want = O.rows(iq, 1, n, mode=O.MODE_MAG_NODC)[0]
-        parity.check_float(row, want)
         u = (iq ^ np.uint8(0x80)).astype(np.float64) / 256.0
         assert abs(np.sum(row * row) - n * np.sum(u * u)) / (n * np.sum(u * u)) < 2e-6
+    _compare_every_row_of_a_periodic_stream(d_out, nf, n, per_chunk,
+                                            O.rows_mt(stream[: 2 * ((per_chunk - 1) * hop + n)], per_chunk, n, hop=hop,
+                                                      mode=O.MODE_MAG_NODC), np.float32)
     d_in.free()
     d_out.free()
     plan.close()
@@ -1190,7 +1211,8 @@ def test_config_c5_stft_16384_at_full_size():
 def test_config_c4_broad_sweep_at_full_size():
     """BASELINE config 4 on one GPU at its full size: 512 centre frequencies x 256 frames x 4096 points
     -> u8 dB tiles (DB5 + DC fix) -> stitched 256 x 2 097 152 image (c/fft-stitch-broad.c geometry).
-    Sampled rows of sampled tiles against the oracle, and the stitch against the tile stack."""
+    EVERY row of every tile against the oracle (the captures repeat with a period of 8192 frames: the oracle transforms
+    one period on the host's cores, all sixteen repetitions are compared with it), and the stitch against the tile stack."""
     n, rows, tiles = 4096, 256, 512
     chunk = synth_iq(4, 1 << 26)                              # 8192 frames of IQ, repeated 16 times = 1 GiB
     d_in = _repeat_upload(chunk, 16)
@@ -1206,13 +1228,13 @@ def test_config_c4_broad_sweep_at_full_size():
     plan.synchronize()
     rng = np.random.default_rng(44)
     per_chunk = (chunk.size // 2) // n                        # 8192 frames per chunk period
+    want = O.rows_mt(chunk, per_chunk, n, mode=O.MODE_DB5_U8_DCFIX)
+    _compare_every_row_of_a_periodic_stream(d_px, tiles * rows, n, per_chunk, want, np.uint8, slab=2048)
     for k in sorted({0, 1, 255, 256, 511, *rng.integers(0, tiles, 6)}):
         for y in sorted({0, rows - 1, *rng.integers(0, rows, 3)}):
             k, y = int(k), int(y)
             f = k * rows + y
             tile_row = _rows_from_device(d_px, [f], n, np.uint8)[0]
-            g = f % per_chunk
-            parity.check_u8(tile_row, O.rows(chunk[2 * g * n: 2 * (g + 1) * n], 1, n, mode=O.MODE_DB5_U8_DCFIX)[0])
             img_row = np.empty(n, np.uint8)
             fsea._check(L.fsea_copy_to_host(0, img_row.ctypes.data,
                                             ctypes.c_void_p(d_img.ptr.value + y * tiles * n + k * n), n))
