@@ -394,12 +394,13 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
     const fsea::KernelEntry *e = p->entry;
     const bool windowed = p->window_form != 0;
     if (windowed) {
-        if (in_kind != fsea::IN_U8) {
-            return fail(FSEA_EINVAL, "the plan has a taper window: the frequency-shifted and the f64-input entry points take "
-                                     "none (fsea_plan_set_window(plan, NULL) removes it)");
+        if (in_kind == fsea::IN_U8) {
+            kind = windowed_kind(kind);
+            if (!e->fn[kind]) kind = fsea::K_U8_WIN;
+        } else {
+            // the nrf_freq_shifter -> nrf_fft chain and the F64 branch of nrf_fft_process (src/nrf.c:607-612) with the taper
+            kind = in_kind == fsea::IN_F32 ? fsea::K_F32_WIN : fsea::K_U8_ROT_WIN;
         }
-        kind = windowed_kind(kind);
-        if (!e->fn[kind]) kind = fsea::K_U8_WIN;
     }
     // tuning variants carry the u8 MAG and run-time-mode kernels only: their pixel modes run the latter
     if (!e->fn[kind] && (kind == fsea::K_U8_DB5 || kind == fsea::K_U8_DB10)) kind = fsea::K_U8;
@@ -706,7 +707,10 @@ int fsea_plan_destroy(fsea_plan *p) {
 
 size_t fsea_plan_row_bytes(const fsea_plan *p) { return p ? (size_t)p->n * mode_elem_bytes(p->mode) : 0; }
 int fsea_plan_fft_size(const fsea_plan *p) { return p ? p->n : 0; }
-const char *fsea_plan_kernel_name(const fsea_plan *p) { return p ? p->kernel_name.c_str() : ""; }
+const char *fsea_plan_kernel_name(const fsea_plan *p) {
+    if (!p) return "";
+    return (p->window_form != 0 && !p->kernel_name_win.empty()) ? p->kernel_name_win.c_str() : p->kernel_name.c_str();
+}
 
 int fsea_plan_set_unit_distribution(fsea_plan *p, int policy) {
     if (!p) return fail(FSEA_EINVAL, "plan is NULL");
@@ -751,7 +755,6 @@ int fsea_plan_set_window(fsea_plan *p, const float *w) {
     FSEA_HIP(hipDeviceSynchronize());  // no launch of this plan may still be reading the tables that are replaced
     if (!w) {
         p->window_form = 0;
-        p->kernel_name = pow2_kernel_name(p);
         return FSEA_OK;
     }
     if (!e->fn[fsea::K_U8_WIN] || !e->fn[fsea::K_U8_MAG_WIN]) {
@@ -769,7 +772,7 @@ int fsea_plan_set_window(fsea_plan *p, const float *w) {
     FSEA_HIP(hipMemcpy(p->d_win, perm.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     FSEA_HIP(hipMemcpy(p->d_win_dc, dc.data(), dc.size() * sizeof(fsea::cf), hipMemcpyHostToDevice));
     p->window_form = form;
-    p->kernel_name = pow2_kernel_name(p);
+    if (p->kernel_name_win.empty()) p->kernel_name_win = pow2_kernel_name(p);
     return FSEA_OK;
 }
 
@@ -780,7 +783,8 @@ int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned
     if (!p->entry->fn[k]) k = p->window_form ? fsea::K_U8_WIN : fsea::K_U8;
     if (grid) *grid = grid_for(p, p->entry, p->occ[k], n_frames);
     if (block) *block = (unsigned)p->entry->wg;
-    if (lds_bytes) *lds_bytes = p->entry->lds_bytes;
+    // a plan with a taper launches the *_WIN kernels, whose static LDS carries the DC table on top
+    if (lds_bytes) *lds_bytes = (p->window_form != 0 && p->entry->lds_bytes_win) ? p->entry->lds_bytes_win : p->entry->lds_bytes;
     return FSEA_OK;
 }
 

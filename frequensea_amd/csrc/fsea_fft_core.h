@@ -591,8 +591,16 @@ __device__ __forceinline__ cf turn_phasor_f32(double turns) {
 template <class Cfg, int IN, int MODE_T = -1, bool ROT = false, bool RUNS = false, int WIN = 0>
 struct FftKernel {
     static_assert(!ROT || IN == IN_U8, "the fused frequency shift is a u8-input path");
-    static_assert(WIN == 0 || (IN == IN_U8 && !ROT && Cfg::TWR && (Cfg::OPT & opt::TUNE_ONLY) == 0 && Cfg::P >= 8),
-                  "the windowed kernels: u8 input, V1 schedule, register-resident (prescaled) last-pass twiddles");
+    static_assert(WIN == 0 || (Cfg::TWR && (Cfg::OPT & opt::TUNE_ONLY) == 0 && Cfg::P >= 8),
+                  "the windowed kernels: V1 schedule, register-resident last-pass twiddles");
+    static_assert(WIN == 0 || !RUNS || (IN == IN_U8 && !ROT), "windowed half-overlap runs: the plain u8 kernel only");
+    // which windowed kernels put the DC term 0.5 (1 + i) D[k] back from FftArgs::win_dc: the u8 kernels (the offset-binary
+    // bytes' own DC) and the frequency-shifted ones (the shifter's + 0.5 (1 + i), src/nrf.c:857-858); f32-complex input has none
+    static constexpr bool WIN_DC = WIN != 0 && IN == IN_U8;
+    // f32-complex input with a taper: the next frame's rows (64 VGPRs of prefetch at 32 points per lane) are requested behind
+    // the row stores instead of behind pass 0 -- with the 32 resident weights on top they would not fit, and this kernel is
+    // the NUT_BUFFER_F64 branch of nrf_fft_process (src/nrf.c:607-612): one frame per call, nothing to prefetch
+    static constexpr bool LATE_LOAD = WIN != 0 && IN == IN_F32;
     static_assert(!RUNS || (IN == IN_U8 && !ROT && Cfg::FPW == 1 && (Cfg::R(0) % 2) == 0), "half-overlap runs: u8 input, one frame per workgroup");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
     static constexpr int LAST = NP - 1;
@@ -1151,9 +1159,9 @@ struct FftKernel {
         // Requested in front of unit 0's bytes: they come from L2 and must not queue behind the HBM burst of the launch's start.
         [[maybe_unused]] const rsrc_t win_rs = buffer_window(WIN ? a.win : nullptr, 0, WIN ? (size_t)N * 4u : 0);
         cf wv[WPAIRS];
-        cf dcv[WIN ? DC_REGS : 1];
-        if constexpr (WIN != 0) {
-            load_window(win_rs, t, wv);
+        cf dcv[WIN_DC ? DC_REGS : 1];
+        if constexpr (WIN != 0) load_window(win_rs, t, wv);
+        if constexpr (WIN_DC) {
 #pragma unroll
             for (int i = 0; i < DC_REGS; ++i) {
                 const int e = tid + i * Cfg::WG;
@@ -1178,7 +1186,7 @@ struct FftKernel {
                 // lanes past the end rewrite the last entry with its own value (loaded clamped above)
                 lds_all[FPW * Cfg::LDS_FRAME + (e < TAB_COPY ? e : TAB_COPY - 1)] = tabv[i];
             }
-            if constexpr (WIN != 0) {
+            if constexpr (WIN_DC) {
 #pragma unroll
                 for (int i = 0; i < DC_REGS; ++i) {
                     const int e = tid + i * Cfg::WG;
@@ -1227,7 +1235,7 @@ struct FftKernel {
             for (int c = 0; c < C0; ++c) {
                 const unsigned n0 = (unsigned)(C0 * t + c);
                 const cf e = turn_phasor_f64(a.rot_delta * (double)n0);
-                ebase[c] = (n0 & 1u) ? -e : e;
+                ebase[c] = (WIN == 0 && (n0 & 1u)) ? -e : e;  // windowed: the (-1)^n rides on the weights (FftArgs::win)
             }
         }
 
@@ -1289,8 +1297,16 @@ struct FftKernel {
                     for (int c = 0; c < C0; ++c) {
                         // u8 = (u8 - 128) + 128: the shifter rotates the offset-binary value itself
                         v[r * C0 + c] = pk_cmul(v[r * C0 + c] + cf{128.0f, 128.0f}, pk_cmul_uniform(fr[c], wr));
+                        if constexpr (WIN != 0) {
+                            // a taper whose DC spectrum does not fit the win_dc band: the shifter's + 0.5 (1 + i) -- 128 in
+                            // byte units -- goes through the transform with the sample (the u8 kernels' offset-binary form)
+                            if (a.win_offset != 0) v[r * C0 + c] += cf{128.0f, 128.0f};
+                        }
                     }
                 }
+            } else if constexpr (WIN != 0 && IN == IN_F32) {
+#pragma unroll
+                for (int r = 0; r < R0; ++r) convert_row<IN, C0, false>(raw[r], 0u, C0 * t, v + r * C0);  // sign: in the weights
             } else if constexpr (WIN != 0) {
                 if (a.win_offset != 0) convert_windowed<true>(raw, xormask, t, v);
                 else convert_windowed<false>(raw, xormask, t, v);
@@ -1337,7 +1353,7 @@ struct FftKernel {
                 } else {
                     load_raw(rs, in_voff, raw);
                 }
-            } else if constexpr ((Cfg::ABL & abl::NO_LOADS) == 0) {  // (measurement only: the first unit's bytes are reused)
+            } else if constexpr ((Cfg::ABL & abl::NO_LOADS) == 0 && !LATE_LOAD) {  // (NO_LOADS, measurement only: the first unit's bytes are reused)
                 load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
             }
             middle_pass<1>(lds, lds_all, v, a, t, tw1);
@@ -1369,7 +1385,7 @@ struct FftKernel {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & abl::NO_FLOPS) != 0>(v + c);
             }
-            if constexpr (WIN != 0) {
+            if constexpr (WIN_DC) {
                 // the offset-binary DC term's spectrum, for this lane's bins of the two rows around N/2
                 // (two bins at a time: the 2 CL values in flight at once cost spills at 1024 points, CL = 4)
                 constexpr int CB = CL >= 2 ? 2 : 1;
@@ -1384,6 +1400,8 @@ struct FftKernel {
                         v[(RL / 2) * CL + c + j] += dc_hi[j];
                     }
                 }
+            }
+            if constexpr (WIN != 0) {
                 if constexpr (WIN == 1) {
                     // the next frame's weights: requested in front of this frame's row stores (loads return in order, and a
                     // wait for a load issued behind the stores would wait for those as well)
@@ -1392,6 +1410,9 @@ struct FftKernel {
                 }
             }
             epilogue(mode, buffer_window(a.out, (size_t)esz * row_elem(RUNS ? fcur : u * FPW), total_out), out_elem, v, tl);
+            if constexpr (LATE_LOAD) {
+                load_raw(buffer_window(a.in, (size_t)IN_BPS * (un * FPW) * a.hop, un < n_units ? total_in : 0), in_voff, raw);
+            }
             u = un;
             if constexpr (RUNS) {
                 fcur = fnext;

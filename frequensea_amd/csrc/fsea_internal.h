@@ -138,8 +138,10 @@ struct fsea_plan {
     float *d_win = nullptr;
     fsea::cf *d_win_dc = nullptr;
     int window_form = 0;
-    std::string kernel_name;
-    std::string kernel_name_nowin;   // kernel_name while no window is set
+    // both strings live as long as the plan: fsea_plan_kernel_name hands out a pointer into the one in use, and a pointer a
+    // caller got earlier stays valid across fsea_plan_set_window (the windowed name depends on the plan's constants only)
+    std::string kernel_name;        // while no window is set
+    std::string kernel_name_win;    // while one is (filled by the first fsea_plan_set_window)
 };
 
 

@@ -17,9 +17,12 @@ namespace fsea {
 // K_U8_MAG_HALF: the MAG kernel for 50 %-overlapped frames (hop == N/2) of the sizes with one frame per workgroup (8192,
 // 16384): runs of consecutive frames per workgroup, every sample loaded once (FftKernel<..., RUNS = true>).
 // K_U8_MAG_WIN, K_U8_WIN, K_U8_MAG_HALF_WIN, K_U8_DB5_WIN, K_U8_DB10_WIN: the u8 kernels with the taper window fused into
-// pass 0 (FftKernel<..., WIN>; fsea_plan_set_window) -- what a plan with a window launches.
+// pass 0 (FftKernel<..., WIN>; fsea_plan_set_window) -- what a plan with a window launches.  K_U8_ROT_WIN, K_F32_WIN: the
+// frequency-shifted and the f32-complex-input kernels with the same taper (the nrf_freq_shifter -> nrf_fft chain of
+// lua/fft-shifted.lua:52-55 and nrf_fft_process' F64 branch, src/nrf.c:607-612, on a plan with a window).
 enum : int { K_U8_MAG = 0, K_U8_DB5 = 1, K_U8_DB10 = 2, K_U8 = 3, K_U8_ROT = 4, K_F32 = 5, K_U8_MAG_HALF = 6,
-             K_U8_MAG_WIN = 7, K_U8_WIN = 8, K_U8_MAG_HALF_WIN = 9, K_U8_DB5_WIN = 10, K_U8_DB10_WIN = 11, K_COUNT = 12 };
+             K_U8_MAG_WIN = 7, K_U8_WIN = 8, K_U8_MAG_HALF_WIN = 9, K_U8_DB5_WIN = 10, K_U8_DB10_WIN = 11,
+             K_U8_ROT_WIN = 12, K_F32_WIN = 13, K_COUNT = 14 };
 
 struct KernelEntry {
     int n;                 // transform size
@@ -27,6 +30,7 @@ struct KernelEntry {
     int t, fpw, wg, np;
     int radix[4];
     size_t lds_bytes;
+    size_t lds_bytes_win;  // static LDS of the *_WIN kernels (the DC table on top); 0 = no windowed kernels
     int c0;                // samples per pass-0 load (hop must be a multiple)
     int counters;          // ticket counters: 0 = never used (single-wave frames), 1 = by launches with FftArgs::dynamic_units,
                            // 2 = by every launch (the V2 schedule and the progress-word experiments of the tuning library)
@@ -52,7 +56,7 @@ struct KernelEntry {
 #define FSEA_KERNEL_ENTRY_HEAD_(NAME, VARIANT)                                                        \
     NAME##_cfg::N, VARIANT, NAME##_cfg::T, NAME##_cfg::FPW, NAME##_cfg::WG, NAME##_cfg::NP,           \
         {NAME##_cfg::R(0), NAME##_cfg::R(1), NAME##_cfg::R(2), NAME##_cfg::R(3)},                     \
-        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC, NAME##_cfg::C(0),                                   \
+        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC, 0, NAME##_cfg::C(0),                                 \
         fsea::FftKernel<NAME##_cfg, fsea::IN_U8>::counters_used()
 
 // Defines the six __global__ entry points of one configuration, with plain C names so that
@@ -158,14 +162,23 @@ struct KernelEntry {
     FSEA_KERNEL_FN_(NAME, _u8_db5_win, fsea::IN_U8, fsea::MODE_DB5_U8_DCFIX, false, false, WMODE)     \
     FSEA_KERNEL_FN_(NAME, _u8_db10_win, fsea::IN_U8, fsea::MODE_DB10_U8, false, false, WMODE)         \
     FSEA_KERNEL_FN_(NAME, _u8_win, fsea::IN_U8, -1, false, false, WMODE)                              \
+    FSEA_KERNEL_FN_(NAME, _u8_rot_win, fsea::IN_U8, -1, true, false, WMODE)                           \
+    FSEA_KERNEL_FN_(NAME, _f32_win, fsea::IN_F32, -1, false, false, WMODE)                            \
     static void NAME##_launch_win(int kind, const fsea::FftArgs &a, unsigned grid, hipStream_t s) {   \
         const dim3 g(grid), b(NAME##_cfg::WG);                                                        \
         if (kind == fsea::K_U8_MAG_WIN) hipLaunchKernelGGL(NAME##_u8_mag_win, g, b, 0, s, a);         \
         else if (kind == fsea::K_U8_DB5_WIN) hipLaunchKernelGGL(NAME##_u8_db5_win, g, b, 0, s, a);    \
         else if (kind == fsea::K_U8_DB10_WIN) hipLaunchKernelGGL(NAME##_u8_db10_win, g, b, 0, s, a);  \
+        else if (kind == fsea::K_U8_ROT_WIN) hipLaunchKernelGGL(NAME##_u8_rot_win, g, b, 0, s, a);    \
+        else if (kind == fsea::K_F32_WIN) hipLaunchKernelGGL(NAME##_f32_win, g, b, 0, s, a);          \
         else hipLaunchKernelGGL(NAME##_u8_win, g, b, 0, s, a);                                        \
     }                                                                                                 \
     static void NAME##_add_win(fsea::KernelEntry &e) {                                                \
+        e.fn[fsea::K_U8_ROT_WIN] = reinterpret_cast<const void *>(&NAME##_u8_rot_win);                \
+        e.fn[fsea::K_F32_WIN] = reinterpret_cast<const void *>(&NAME##_f32_win);                      \
+        e.name[fsea::K_U8_ROT_WIN] = #NAME "_u8_rot_win";                                             \
+        e.name[fsea::K_F32_WIN] = #NAME "_f32_win";                                                   \
+        e.lds_bytes_win = sizeof(fsea::cf) * fsea::FftKernel<NAME##_cfg, fsea::IN_U8, fsea::MODE_MAG, false, false, WMODE>::LDS_CF; \
         e.fn[fsea::K_U8_MAG_WIN] = reinterpret_cast<const void *>(&NAME##_u8_mag_win);                \
         e.fn[fsea::K_U8_DB5_WIN] = reinterpret_cast<const void *>(&NAME##_u8_db5_win);                \
         e.fn[fsea::K_U8_DB10_WIN] = reinterpret_cast<const void *>(&NAME##_u8_db10_win);              \

@@ -19,6 +19,14 @@
  * f32 plus one widening.  Same results bit for bit; which one is faster
  * depends on how often get_buffer is called per process (profiles/,
  * scripts/nrf_latency.py): the default is the host ring.
+ *
+ * NRF_FFT_WINDOW=hann|hamming|blackman|blackmanharris|flattop in the environment
+ * puts that taper beside the (-1)^ii of the unpack loop (src/nrf.c:601-614),
+ * for U8 and F64 buffers alike (so the nrf_freq_shifter -> nrf_fft chain of
+ * lua/fft-shifted.lua:52-55 is tapered too) and in both history modes:
+ * fsea_plan_set_window on the block's plan, fused into the kernel's pass 0.
+ * Unset (or "rect" / "none") is the reference: it has no taper, the API keeps
+ * its signatures, and the scenes need no change to get one.
  */
 #include <math.h>
 #include <stdio.h>
@@ -56,6 +64,31 @@ nrf_fft *nrf_fft_new(int fft_size, int fft_history_size) {
     int rc = fsea_plan_create(&plan, fft_size, fft_size, FSEA_MODE_MAG_F32, dev_env ? atoi(dev_env) : 0);
     if (rc != FSEA_OK) fsea_fatal("fsea_plan_create", rc);
     fft->backend = plan;
+    const char *win_env = getenv("NRF_FFT_WINDOW");
+    if (win_env != NULL && win_env[0] != '\0' && strcmp(win_env, "rect") != 0 && strcmp(win_env, "none") != 0) {
+        static const struct { const char *name; int kind; } tapers[] = {
+            {"hann", FSEA_WINDOW_HANN},           {"hamming", FSEA_WINDOW_HAMMING}, {"blackman", FSEA_WINDOW_BLACKMAN},
+            {"blackmanharris", FSEA_WINDOW_BLACKMANHARRIS}, {"flattop", FSEA_WINDOW_FLATTOP}};
+        int kind = -1;
+        for (size_t i = 0; i < sizeof(tapers) / sizeof(tapers[0]); i++) {
+            if (strcmp(win_env, tapers[i].name) == 0) kind = tapers[i].kind;
+        }
+        if (kind < 0) {
+            fprintf(stderr, "NRF FFT fatal error: NRF_FFT_WINDOW=%s is not one of hann, hamming, blackman, blackmanharris, "
+                            "flattop, rect\n", win_env);
+            exit(EXIT_FAILURE);
+        }
+        float *w = (float *)malloc(sizeof(float) * (size_t)fft_size);
+        if (w == NULL) {
+            fprintf(stderr, "NRF FFT fatal error: out of memory\n");
+            exit(EXIT_FAILURE);
+        }
+        rc = fsea_window_fill(kind, fft_size, w);
+        if (rc != FSEA_OK) fsea_fatal("fsea_window_fill", rc);
+        rc = fsea_plan_set_window(plan, w); /* fails for a size without a kernel of its own: said loudly, not ignored */
+        if (rc != FSEA_OK) fsea_fatal("fsea_plan_set_window (NRF_FFT_WINDOW)", rc);
+        free(w);
+    }
     const char *hist_env = getenv("NRF_FFT_HISTORY");
     if (hist_env != NULL && strcmp(hist_env, "device") == 0) {
         fsea_history *hist = NULL;

@@ -105,9 +105,13 @@ int fsea_plan_destroy(fsea_plan *plan);
  * The multiply is fused into the kernel's byte conversion (one packed multiply per sample; no extra pass, no extra
  * HBM traffic: the fft_size weights live in L2 / registers).
  *   w: fft_size floats, copied; NULL removes the window (rectangular, the un-windowed kernels).  Any finite values.
- * Applies to fsea_exec_u8_device, fsea_exec_u8_tiled_device, fsea_exec_u8_host, the history ring and the gate.  The
- * frequency-shifted and the f64-input entry points fail with FSEA_EINVAL on a plan with a window, and so does
- * fsea_plan_set_window on a plan whose size has no kernel of its own (not a power of two in [32, 16384]).
+ * Applies to every transform of the plan: fsea_exec_u8_device, fsea_exec_u8_tiled_device, fsea_exec_u8_host, the history
+ * ring, the gate, and -- since round 5 -- the frequency-shifted entry points (fsea_exec_u8_shifted_*: x[n] = (-1)^n w[n]
+ * ((u8/256) e^{i phi} + 0.5 (1 + i)), kernels `*_u8_rot_win`) and the f64-input one (fsea_exec_f64_host: x[n] = (-1)^n
+ * w[n] f64[n], src/nrf.c:607-612 with the taper beside the sign, kernels `*_f32_win`), i.e. the whole
+ * nrf_freq_shifter -> nrf_fft chain of lua/fft-shifted.lua:52-55.  fsea_plan_set_window fails with FSEA_EINVAL on a plan
+ * whose size has no kernel of its own (not a power of two in [32, 16384]).  fsea_plan_kernel_name's pointer stays valid
+ * across this call (both names live as long as the plan); what it points to is the name in use when it was asked.
  * Synchronous (waits for the device); not to be called while another thread is launching the plan.
  * Precision: the kernels transform w[n] (u8[n] - 128) and add the offset-binary DC term back as its known spectrum
  * (computed in double at this call) when that spectrum is confined to the bins around n/2 -- every cosine-sum

@@ -49,6 +49,10 @@ void orc_unpack_center_f64(const double *iq, size_t n_samples, double *out) {
     }
 }
 
+/* nrf_fft_process' F64 branch (src/nrf.c:607-612) on whole rows, with an optional taper beside the (-1)^ii (window NULL:
+ * the reference): frame f = complex samples [f*hop, f*hop + n) of iq (interleaved doubles).  Modes and out as orc_rows. */
+int orc_rows_f64(const double *iq, size_t n_frames, int n, size_t hop, int mode, const double *window, void *out);
+
 /* ---- a5 ------------------------------------------------------------- */
 
 static int ilog2_exact(int n) {
@@ -318,6 +322,32 @@ int orc_rows(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip,
     return 0;
 }
 
+int orc_rows_f64(const double *iq, size_t n_frames, int n, size_t hop, int mode, const double *window, void *out) {
+    orc_plan p;
+    if (mode < 0 || mode > 5) return -2;
+    if (orc_plan_init(&p, n) != 0) return -1;
+    double *tmp_in = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tmp_out = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    size_t row_bytes = (mode == 1 || mode == 2) ? (size_t)n
+                       : (mode == 3)            ? sizeof(double) * 2 * (size_t)n
+                                                : sizeof(double) * (size_t)n;
+    for (size_t f = 0; f < n_frames; f++) {
+        orc_unpack_center_f64(iq + 2 * f * hop, (size_t)n, tmp_in); /* src/nrf.c:607-612 */
+        if (window != NULL) {
+            for (int k = 0; k < n; k++) {
+                tmp_in[2 * k] *= window[k];
+                tmp_in[2 * k + 1] *= window[k];
+            }
+        }
+        orc_plan_exec(&p, tmp_in, tmp_out);
+        orc_epilogue(n, mode, tmp_out, (uint8_t *)out + f * row_bytes);
+    }
+    free(tmp_in);
+    free(tmp_out);
+    orc_plan_free(&p);
+    return 0;
+}
+
 /* ---- taper window (extension: BASELINE.json north_star / config 5; the reference's only weight is (-1)^ii) ---- */
 
 int orc_rows_windowed(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
@@ -397,6 +427,11 @@ void orc_freq_shift(const uint8_t *iq_u8, const double *iq_f64, size_t n_samples
 
 int orc_rows_shifted(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
                      double cycles_per_sample, double phase0_cycles, void *out) {
+    return orc_rows_shifted_windowed(iq, n_frames, n, hop, flip, mode, cycles_per_sample, phase0_cycles, NULL, out);
+}
+
+int orc_rows_shifted_windowed(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                              double cycles_per_sample, double phase0_cycles, const double *window, void *out) {
     orc_plan p;
     if (mode < 0 || mode > 5) return -2;
     if (orc_plan_init(&p, n) != 0) return -1;
@@ -419,7 +454,13 @@ int orc_rows_shifted(const uint8_t *iq, size_t n_frames, int n, size_t hop, int 
             shifted[2 * k] = vi * c - vq * s + 0.5;
             shifted[2 * k + 1] = vi * s + vq * c + 0.5;
         }
-        orc_unpack_center_f64(shifted, (size_t)n, tmp_in);
+        orc_unpack_center_f64(shifted, (size_t)n, tmp_in); /* src/nrf.c:607-612 */
+        if (window != NULL) {                              /* the weight beside the (-1)^ii */
+            for (int k = 0; k < n; k++) {
+                tmp_in[2 * k] *= window[k];
+                tmp_in[2 * k + 1] *= window[k];
+            }
+        }
         orc_plan_exec(&p, tmp_in, tmp_out);
         orc_epilogue(n, mode, tmp_out, (uint8_t *)out + f * row_bytes);
     }

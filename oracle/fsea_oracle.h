@@ -137,6 +137,17 @@ void orc_freq_shift(const uint8_t *iq_u8, const double *iq_f64, size_t n_samples
 int orc_rows_shifted(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
                      double cycles_per_sample, double phase0_cycles, void *out);
 
+/* orc_rows_shifted with a taper beside the (-1)^n of the F64 branch (window == NULL: orc_rows_shifted itself):
+ *   x[n] = (-1)^n * window[n] * ( (u8[m]/256) * e^{+2 pi i (...)} + 0.5 (1+i) )
+ * -- the nrf_freq_shifter -> nrf_fft chain of lua/fft-shifted.lua:52-55 on a plan with a window.  An extension, as
+ * orc_rows_windowed. */
+int orc_rows_shifted_windowed(const uint8_t *iq, size_t n_frames, int n, size_t hop, int flip, int mode,
+                              double cycles_per_sample, double phase0_cycles, const double *window, void *out);
+
+/* nrf_fft_process' F64 branch (src/nrf.c:607-612: x[ii] = (-1)^ii * f64) on whole rows, with an optional taper beside the
+ * sign (window == NULL: the reference): frame f = complex samples [f*hop, f*hop + n) of iq (interleaved doubles). */
+int orc_rows_f64(const double *iq, size_t n_frames, int n, size_t hop, int mode, const double *window, void *out);
+
 /* The reference-shaped per-frame loop used as bench.py's cpu_baseline
  * ("port"): a1 flip -> a4 unpack (n samples) -> a5 FFT -> a7 magnitude, on
  * one core, with a pre-planned twiddle table.  Returns seconds elapsed for

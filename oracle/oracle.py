@@ -335,6 +335,57 @@ def rows_shifted(iq, n_frames, n, cycles_per_sample, phase0_cycles=0.0, hop=None
     return out
 
 
+def _rows_out(mode, n_frames, n):
+    if mode in (MODE_DB10_U8, MODE_DB5_U8_DCFIX):
+        return np.empty((n_frames, n), dtype=np.uint8)
+    if mode == MODE_COMPLEX:
+        return np.empty((n_frames, n), dtype=np.complex128)
+    return np.empty((n_frames, n), dtype=np.float64)
+
+
+def rows_shifted_windowed(iq, n_frames, n, cycles_per_sample, window, phase0_cycles=0.0, hop=None, flip=True, mode=MODE_MAG):
+    """rows_shifted() with a taper beside the (-1)^n: x[j] = (-1)^j window[j] (shifter output)[j]."""
+    hop = n if hop is None else hop
+    iq = np.ascontiguousarray(iq, dtype=np.uint8).ravel()
+    need = 2 * ((n_frames - 1) * hop + n) if n_frames else 0
+    if iq.size < need:
+        raise ValueError("iq too short: %d < %d" % (iq.size, need))
+    w = np.ascontiguousarray(window, dtype=np.float64)
+    if w.size != n:
+        raise ValueError("window must have n weights")
+    out = _rows_out(mode, n_frames, n)
+    L = lib()
+    L.orc_rows_shifted_windowed.restype = ctypes.c_int
+    L.orc_rows_shifted_windowed.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.orc_rows_shifted_windowed(iq.ctypes.data, n_frames, n, hop, int(bool(flip)), mode, cycles_per_sample,
+                                     phase0_cycles, w.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise ValueError("orc_rows_shifted_windowed failed: %d" % rc)
+    return out
+
+
+def rows_f64(x, n_frames, n, hop=None, mode=MODE_MAG, window=None):
+    """Whole rows of nrf_fft_process' F64 branch (interleaved f64 IQ), with an optional taper beside the (-1)^n."""
+    hop = n if hop is None else hop
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    need = 2 * ((n_frames - 1) * hop + n) if n_frames else 0
+    if x.size < need:
+        raise ValueError("iq too short: %d < %d" % (x.size, need))
+    w = None if window is None else np.ascontiguousarray(window, dtype=np.float64)
+    if w is not None and w.size != n:
+        raise ValueError("window must have n weights")
+    out = _rows_out(mode, n_frames, n)
+    L = lib()
+    L.orc_rows_f64.restype = ctypes.c_int
+    L.orc_rows_f64.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_int,
+                               ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.orc_rows_f64(x.ctypes.data, n_frames, n, hop, mode, None if w is None else w.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise ValueError("orc_rows_f64 failed: %d" % rc)
+    return out
+
+
 def time_mag_rows(iq, n_frames, n, hop=None, threads=1):
     """cpu_baseline leg: seconds for n_frames reference-shaped rows."""
     hop = n if hop is None else hop

@@ -112,8 +112,12 @@ static inline int dispatch(int in_kind, int mode_t, const fsea::FftArgs &a, unsi
     } else
     if (!g_window.empty()) {  // windowed kernels: K_U8_MAG_WIN / K_U8_DB5_WIN / K_U8_DB10_WIN (compile-time mode), K_U8_WIN, K_U8_MAG_HALF_WIN
         if constexpr ((Cfg::OPT & (64 | 1048576 | 8388608)) == 0 && Cfg::TWR) {
-            if ((int)g_window.size() != Cfg::N || (in_kind != fsea::IN_U8 && in_kind != 3)) return -5;
-            if (in_kind == 3) {
+            if ((int)g_window.size() != Cfg::N) return -5;
+            if (in_kind == fsea::IN_U8_ROT) {         // K_U8_ROT_WIN: the fused frequency shift with the taper
+                run_grid<Cfg, fsea::IN_U8, -1, true, false, 2>(a, grid);
+            } else if (in_kind == fsea::IN_F32) {     // K_F32_WIN: f32-complex input with the taper
+                run_grid<Cfg, fsea::IN_F32, -1, false, false, 2>(a, grid);
+            } else if (in_kind == 3) {
                 if constexpr (Cfg::FPW == 1 && (Cfg::OPT & 512) == 0) {
                     if (g_window_mode == 1) run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, true, 1>(a, grid);
                     else run_grid<Cfg, fsea::IN_U8, fsea::MODE_MAG, false, true, 2>(a, grid);

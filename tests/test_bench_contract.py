@@ -101,7 +101,18 @@ def test_bench_with_two_ranks_runs_the_sharded_sweep_and_stream_with_a_gather():
     assert ex["broad_sweep_ms_resident"] > 0 and ex["broad_sweep_ms_ingest"] > 0 and ex["stft_stream_ms"] > 0
     assert ex["gather_gbps_per_link"] > 0 and ex["gather_bytes_per_peer"] == 256 * 256 * 4096
     assert "resident" in ex["regime"]["broad_sweep_ms_resident"] and "ingest" in ex["regime"]["broad_sweep_ms_ingest"]
-    # the sweep's image does not depend on how many ranks made it: same checksum as the one-rank line's (next test)
+    assert ex["broad_sweep_resident_gathered_checksum"] == ex["broad_sweep_ingest_gathered_checksum"]
+    _same_image_at_every_world_size(2, ex["broad_sweep_resident_gathered_checksum"])
+
+
+_IMAGE_CHECKSUMS = {}
+
+
+def _same_image_at_every_world_size(world, checksum):
+    """The sweep's captures are seeded per centre frequency, so the stitched image -- and its checksum in the line -- must not
+    depend on how many ranks made it (whichever of the two bench tests runs second compares)."""
+    _IMAGE_CHECKSUMS[world] = checksum
+    assert len(set(_IMAGE_CHECKSUMS.values())) == 1, _IMAGE_CHECKSUMS
 
 
 @pytest.mark.gpu
@@ -146,6 +157,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert ex["multi_gpu_error"] is None and ex["rccl_world"] == 1 and ex["gather_gbps_per_link"] is None
     assert ex["broad_sweep_resident_gathered_checksum_ok"] is True and ex["stft_stream_gathered_checksum_ok"] is True
     assert abs(ex["broad_sweep_ms_resident"] - ex["broad_sweep_1gpu_ms"]) < 1e-12 and ex["broad_sweep_ms_ingest"] > ex["broad_sweep_ms_resident"]
+    _same_image_at_every_world_size(1, ex["broad_sweep_resident_gathered_checksum"])
     # independent batches on two streams: one launch's drain under the next one's ramp; beside `value`, never in it
     assert 0.9 * d["value"] < ex["two_stream_frames_per_sec_n8192"] < 1.3 * d["value_events"]
     assert 0.1 < ex["stft16384_roofline_frac"] < 1.0 and 0.1 < ex["broad_sweep_roofline_frac"] < 1.0

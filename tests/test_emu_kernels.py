@@ -313,6 +313,27 @@ def test_windowed_half_overlap_kernel(n):
     parity.check_mode_windowed(got, iq, n, nf, hop, True, 0, w)
 
 
+@pytest.mark.parametrize("n", [32, 256, 1024, 4096, 8192])
+def test_windowed_shifted_and_f32_input_kernels(n):
+    """K_U8_ROT_WIN and K_F32_WIN: the frequency-shifted and the f32-complex-input kernels with the taper (both forms of the
+    DC term for the shifted one) against the oracle."""
+    nf = 3
+    iq = synth_iq(900 + n, 2 * nf * n)
+    for wname, form in (("hann", 0), ("hann", 2)):
+        w = _taper(wname, n)
+        for flip in (True, False):
+            got = emu_rows(iq, n, nf, flip=flip, mode=3, shift=(0.0137, 0.25), window=w, window_form=form, specialised=False)
+            want = O.rows_shifted_windowed(iq, nf, n, 0.0137, w.astype(np.float64), 0.25, flip=flip, mode=O.MODE_COMPLEX)
+            parity.check_float(got, want)
+    x = np.random.default_rng(n).normal(0.2, 0.3, 2 * nf * n).astype(np.float32)
+    w = _taper("blackman", n)
+    got = emu_rows(x, n, nf, mode=0, in_kind=1, specialised=False, window=w)
+    parity.check_float(got, O.rows_f64(x.astype(np.float64), nf, n, window=w.astype(np.float64)))
+    ones = np.ones(n, np.float32)
+    assert np.array_equal(emu_rows(x, n, nf, mode=3, in_kind=1, specialised=False, window=ones),
+                          emu_rows(x, n, nf, mode=3, in_kind=1, specialised=False))
+
+
 def test_windowed_random_geometry_sweep():
     """Seeded random draws of (size, hop, frame count, mode, flip, grid, taper, weight residency) through the windowed
     kernels: overlapped, gapped and tiny hops, ragged frame counts, every epilogue, cosine-sum / arbitrary / signed weights."""

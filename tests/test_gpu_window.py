@@ -226,20 +226,132 @@ def test_windowed_tiles_equal_windowed_rows():
     plan.close()
 
 
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("wname", ["hann", "random"])
+def test_windowed_frequency_shifted_rows(n, wname):
+    """The nrf_freq_shifter -> nrf_fft chain (lua/fft-shifted.lua:52-55; src/nrf.c:843-866, 607-612) on a plan with a taper:
+    x[j] = (-1)^j w[j] ((u8 / 256) e^{i phi} + 0.5 (1 + i)) -- the `*_u8_rot_win` kernels against the oracle's windowed
+    shifted rows, every mode the run-time-mode kernel serves, both byte conventions, both forms of the DC term (cosine sum:
+    the shifter's + 0.5 (1 + i) restored from the window's spectrum; arbitrary weights: carried through the transform)."""
+    nf = 40 if n <= 1024 else 9
+    iq = synth_iq(300 + n, 2 * nf * n)
+    w = _window(wname, n, seed=3)
+    cps, phase0 = 10e3 / 5e6 * (1 + n % 7), 0.3125
+    for mode in (0, 3, 2):
+        plan = fsea.Plan(n, mode=mode)
+        plan.set_window(w)
+        for flip in (True, False):
+            got = plan.exec_shifted_host(iq, nf, cps, phase0, flip=flip)
+            want = O.rows_shifted_windowed(iq, nf, n, cps, np.asarray(w, np.float32).astype(np.float64), phase0, flip=flip,
+                                           mode=parity.ORACLE_MODE[mode])
+            (parity.check_u8 if mode == 2 else parity.check_float)(got, want)
+        if mode == 0:                                # a shift of zero is the un-shifted windowed transform (same tolerance)
+            parity.check_mode_windowed(plan.exec_shifted_host(iq, nf, 0.0), iq, n, nf, n, True, 0, w)
+        plan.close()
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("wname", ["hann", "random"])
+def test_windowed_f64_input_branch(n, wname):
+    """nrf_fft_process' F64 branch (src/nrf.c:607-612: x[ii] = (-1)^ii f64) with the taper beside the sign: the `*_f32_win`
+    kernels against the oracle, magnitude and complex rows; unit weights give the un-windowed kernel's bits."""
+    nf = 25 if n <= 1024 else 6
+    x = np.random.default_rng(n).normal(0.3, 0.2, 2 * nf * n)
+    w = _window(wname, n, seed=5)
+    w64 = np.asarray(w, np.float32).astype(np.float64)
+    for mode in (0, 3):
+        plan = fsea.Plan(n, mode=mode)
+        base = plan.exec_host_f64(x, nf)
+        plan.set_window(w)
+        got = plan.exec_host_f64(x, nf)
+        parity.check_float(got, O.rows_f64(x.astype(np.float32).astype(np.float64), nf, n, mode=parity.ORACLE_MODE[mode], window=w64))
+        plan.set_window(np.ones(n, np.float32))
+        assert np.array_equal(plan.exec_host_f64(x, nf).view(np.uint8), base.view(np.uint8)), (n, mode)
+        plan.close()
+
+
+def test_a_window_of_ones_gives_the_unwindowed_shifted_kernels_bits():
+    for n in (256, 1024, 8192):
+        nf = 12
+        iq = synth_iq(77 + n, 2 * nf * n)
+        plan = fsea.Plan(n)
+        base = plan.exec_shifted_host(iq, nf, 0.0123, 0.4)
+        plan.set_window(np.ones(n, np.float32))
+        got = plan.exec_shifted_host(iq, nf, 0.0123, 0.4)
+        # the DC term comes back from the table's f32 entry instead of the analytic 0.5 N (1 + i): the patched bin aside,
+        # everything else is the same arithmetic
+        assert np.array_equal(base, got), n
+        plan.close()
+
+
+@pytest.mark.parametrize("history", ["host", "device"])
+@pytest.mark.parametrize("taper", ["hann", "blackmanharris"])
+def test_nrf_fft_with_a_taper_from_the_environment(golden, monkeypatch, history, taper):
+    """NRF_FFT_WINDOW (host/nrf_fft.c): the nrf_* API keeps its signatures and the taper reaches "the fft_buffer handed to Lua"
+    -- U8 device blocks, F64 buffers (the nrf_freq_shifter -> nrf_fft chain, lua/fft-shifted.lua:52-55; src/nrf.c:607-612)
+    and the shifter block itself, both history modes, at the sizes the scenes use -- against the windowed oracle."""
+    from frequensea_amd import nrf
+    monkeypatch.setenv("NRF_FFT_HISTORY", history)
+    monkeypatch.setenv("NRF_FFT_WINDOW", taper)
+    L = nrf.nrf_lib()
+    raw = golden["rf_202p500_2__flipped"]                       # device buffers are offset binary
+    for n, h in ((1024, 1024), (128, 512)):
+        w = O.window(taper, n).astype(np.float32).astype(np.float64)
+        fft = L.nrf_fft_new(n, h)
+        buf = L.nut_buffer_new_u8(raw.size // 2, 2, raw.ctypes.data)
+        L.nrf_fft_process(fft, buf)
+        want_u8 = O.rows_windowed(raw, 1, n, w, flip=False)[0]
+        f64 = L.nut_buffer_convert(buf, nrf.NUT_BUFFER_F64)
+        L.nrf_fft_process(fft, f64)
+        x = np.ctypeslib.as_array(f64.contents.data.f64, shape=(raw.size,)).copy()
+        want_f64 = O.rows_f64(x.astype(np.float32).astype(np.float64), 1, n, window=w)[0]
+        shifter = L.nrf_freq_shifter_new(10000, 5000000)
+        L.nrf_freq_shifter_process(shifter, buf)
+        sb = L.nrf_freq_shifter_get_buffer(shifter)
+        L.nrf_fft_process(fft, sb)
+        want_shift = O.rows_shifted_windowed(raw, 1, n, 10000 / 5e6, w, flip=False)[0]
+        out = L.nrf_fft_get_buffer(fft)
+        hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+        L.nut_buffer_free(out)
+        parity.check_float(hist[2], want_u8)
+        parity.check_float(hist[1], want_f64)
+        parity.check_float(hist[0], want_shift)
+        assert not hist[3:].any()
+        for b in (sb, f64, buf):
+            L.nut_buffer_free(b)
+        L.nrf_freq_shifter_free(shifter)
+        L.nrf_fft_free(fft)
+    # unset (or "rect"): the reference's rectangular frames, i.e. the golden rows
+    monkeypatch.setenv("NRF_FFT_WINDOW", "rect")
+    fft = L.nrf_fft_new(1024, 4)
+    buf = L.nut_buffer_new_u8(raw.size // 2, 2, raw.ctypes.data)
+    L.nrf_fft_process(fft, buf)
+    out = L.nrf_fft_get_buffer(fft)
+    parity.check_float(nrf.buffer_to_numpy(L, out).reshape(4, 1024)[0], golden["rf_202p500_2__mag_1024"])
+    L.nut_buffer_free(out)
+    L.nut_buffer_free(buf)
+    L.nrf_fft_free(fft)
+
+
+def test_nrf_fft_refuses_an_unknown_taper_loudly():
+    """The reference's error convention (src/nrf.c:54-78): print and exit(EXIT_FAILURE)."""
+    import subprocess
+    import sys
+    code = "from frequensea_amd import nrf; L = nrf.nrf_lib(); L.nrf_fft_new(1024, 4); print('not reached')"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, NRF_FFT_WINDOW="hamster"), timeout=300)
+    assert r.returncode == 1 and "NRF_FFT_WINDOW=hamster" in r.stderr and "not reached" not in r.stdout
+    r = subprocess.run([sys.executable, "-c", code.replace("1024, 4", "1000, 4")], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, NRF_FFT_WINDOW="hann"), timeout=300)
+    assert r.returncode == 1 and "no kernel of its own" in r.stderr and "not reached" not in r.stdout
+
+
 def test_window_errors():
     plan = fsea.Plan(1024)
     bad = np.ones(1024, np.float32)
     bad[17] = np.nan
     with pytest.raises(fsea.FseaError, match="not finite"):
         plan.set_window(bad)
-    plan.set_window("hann")
-    iq = synth_iq(1, 2 * 4 * 1024)
-    with pytest.raises(fsea.FseaError, match="taper window"):
-        plan.exec_shifted_host(iq, 4, 0.01)
-    with pytest.raises(fsea.FseaError, match="taper window"):
-        plan.exec_host_f64(np.zeros(2 * 4 * 1024), 4)
-    plan.set_window(None)
-    plan.exec_shifted_host(iq, 4, 0.01)
     plan.close()
     odd = fsea.Plan(1000, hop=1000)
     with pytest.raises(fsea.FseaError, match="no kernel of its own"):
