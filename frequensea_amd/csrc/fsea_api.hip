@@ -337,8 +337,11 @@ unsigned *counter_slot(fsea_plan *p, hipStream_t s, int *index, bool *record) {
         p->slots[pick].stream = s;
     }
     fsea_plan::CtrSlot &c = p->slots[pick];
+    // A slot a capture has used stays reserved for its stream until fsea_plan_reset: an instantiated hipGraph has the slot's
+    // counter address baked into its kernel node, so recycling it to another stream (round 4 did, once the capturing stream
+    // launched un-captured again) would let a replay share one counter with that stream's launches.  The
+    // capturing stream itself keeps using it for ordinary launches, in stream order with a replay on that stream.
     if (capturing) c.captured = true;
-    else if (c.captured) c.captured = c.pending = false;  // the stream is launching outside a capture again: the slot is an ordinary one
     if (!capturing && !c.ev) {
         if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
     }

@@ -69,10 +69,21 @@ typedef struct {
  * a writer thread are completed first: an error in one capture must not truncate the image of an earlier one. */
 static png_writer *g_writers[MAX_MEMBERS];
 static pthread_mutex_t g_fatal_mu = PTHREAD_MUTEX_INITIALIZER;
+/* g_writers[] is written by its member thread and read by whichever thread fails: both under g_fatal_mu.  A
+ * member that wants to retire its writer while another thread is already ending the process blocks in writer_retire --
+ * it never gets to png_writer_finish, so the failing thread drains a writer whose thread is still alive. */
+static void writer_register(int member, png_writer *w) {
+    pthread_mutex_lock(&g_fatal_mu);
+    g_writers[member] = w;
+    pthread_mutex_unlock(&g_fatal_mu);
+}
+static void writer_retire(int member) { writer_register(member, NULL); }
 static void fatal_exit(void) {
     pthread_mutex_lock(&g_fatal_mu); /* one thread ends the process; a second fatal error waits here until it has */
     for (int m = 0; m < MAX_MEMBERS; m++) {
-        if (g_writers[m]) png_writer_drain(g_writers[m]);
+        if (g_writers[m] && png_writer_drain_for(g_writers[m], 30.0) != 0) {
+            fprintf(stderr, "fsea-fft-sweep: member %d's tile PNG was still being written after 30 s; leaving it\n", m);
+        }
     }
     exit(EXIT_FAILURE);
 }
@@ -182,7 +193,7 @@ static void *member_main(void *argp) {
     png_writer writer;
     CHECK(capture_reader_start(&reader, mine, member_loader, &rctx, (uint8_t *)packed[0], (uint8_t *)packed[1]) == 0 &&
           png_writer_start(&writer, (uint8_t *)pixels[0], (uint8_t *)pixels[1]) == 0, "member %d: reader / writer threads", me);
-    g_writers[me] = &writer;
+    writer_register(me, &writer);
     CHECK(fsea_plan_create(&plan, n, n, cfg->broad ? FSEA_MODE_DB5_U8_DCFIX : FSEA_MODE_DB10_U8, device) == 0,
           "member %d: fsea_plan_create", me);
     if (cfg->window) {
@@ -281,7 +292,7 @@ static void *member_main(void *argp) {
     /* all transfers complete, all source tiles free again */
     CHECK(fsea_comm_barrier(cfg->comm, me, stream) == 0, "member %d: barrier", me);
     capture_reader_join(&reader);
-    g_writers[me] = NULL;
+    writer_retire(me);
     CHECK(png_writer_finish(&writer) == 0, "member %d: a tile PNG could not be written", me);
     for (int k = 0; k < 2; k++) {
         fsea_host_free(packed[k]);

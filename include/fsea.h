@@ -174,8 +174,10 @@ int fsea_plan_set_unit_distribution(fsea_plan *plan, int policy);
  * being captured into a hipGraph nothing but the kernel is enqueued
  * (launch-bound consumers: tests/test_gpu_parity.py::test_launches_can_be_captured_into_a_hip_graph); a captured
  * launch keeps the ticket-counter slot of the stream it was captured on: replay one instance of such a graph at a
- * time.  A stream that launches outside a capture again gets an ordinary slot back; at most 64 distinct streams may
- * hold captured launches of one plan at a time (fsea_plan_reset releases them all).  Plans of the sizes without a
+ * time, on the stream it was captured on or in order with that stream's other launches of the plan.  The slot stays
+ * reserved for that stream until fsea_plan_reset (the graph's kernel node holds its address; the stream's own un-captured
+ * launches go on using it): at most 64 distinct streams may hold captured launches of one plan (fsea_plan_reset releases
+ * them all and invalidates the graphs).  Plans of the sizes without a
  * kernel of their own (Bluestein / four-step) refuse a capturing stream with FSEA_EINVAL. */
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
                         void *d_out, void *stream);
