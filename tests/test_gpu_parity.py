@@ -1347,26 +1347,36 @@ def test_host_threads_share_and_split_plans(golden):
 
 
 # ---------------------------------------------------------------------------------------------
-# the draw loops of the five FFT scenes, replayed through the C API.  No Lua
-# interpreter exists in the image; what the scripts do per rendered frame is a fixed call chain
-# (src/main.cpp:775-811 binds these C functions one to one), so the chain itself is replayed:
-#   setup():  nrf_device_new(freq, file) -> [nrf_freq_shifter_new] -> nrf_fft_new(N, H)
-#   draw():   nrf_device_get_samples_buffer -> [shifter] -> nrf_fft_process -> nrf_fft_get_buffer
-#             -> ngl_texture_update(texture, fft_buffer, W, H)
-#   retune:   nrf_device_set_frequency + nrf_fft_shift(fft, (sample_rate / 1e6) / d)   (lua/_keys.lua:154-168,
-#             lua/fft-sea.lua:137-141) with live rows in the history
-# against the committed golden rows of the recorded captures.  The consumer contract is
-# ngl_texture_update's (src/ngl.c:224-239): width * height <= buffer.length or exit, and the f64
-# buffer narrowed to f32 element by element.
+# the reference's five FFT scenes, as TRACES OF THE SCRIPTS THEMSELVES.  tests/golden/lua_scene_traces.json was
+# written in the build container by the reference's own vendored Lua 5.3 interpreter running lua/fft.lua, fft-shifted.lua,
+# fft-sea.lua, fft-sea-auto.lua and fft-sea-sick.lua unmodified under a tracing host (oracle/lua_trace.c;
+# tests/golden/make_lua_traces.py): every call into the nrf_* surface with the arguments the C function receives
+# (src/main.cpp:775-811 binds them one to one; nrf_fft_shift's d arrives narrowed to float, main.cpp:788), every
+# ngl_texture_update with its size, the key events and the garbage collections that free buffers.  The replay makes exactly
+# those calls on libfsea_nrf.so and checks every buffer that crosses the boundary against the oracle applied to the same
+# bytes -- and, without a taper, against the checksums the trace recorded.  (Rounds 2-4 replayed a hand-written table of
+# what the scenes were believed to do; the traces show three things it had wrong: fft-sea.lua and fft-sea-auto.lua call
+# nrf_fft_shift(fft, inf) from setup(), fft-sea-auto.lua retunes by 0.01 MHz at the end of EVERY draw, and fft-sea-sick.lua
+# does have a retune handler.)
 # ---------------------------------------------------------------------------------------------
-SCENES = {
-    # name: (N, H, texture W x H, shifter offset Hz or None, retune steps d in MHz as the scene's handlers make them)
-    "fft.lua": (1024, 1024, (1024, 1024), None, [0.1, -0.1, 10.0]),          # _keys.lua: d = 0.1, Shift: 10
-    "fft-shifted.lua": (1024, 1024, (1024, 1024), 0.0, [0.1]),               # shift = 0 at setup (fft-shifted.lua:38)
-    "fft-sea.lua": (128, 512, (128, 512), None, [0.1, 72.2, -0.001]),        # set_freq: arbitrary d (97.6 -> 169.8)
-    "fft-sea-auto.lua": (128, 512, (128, 512), None, [72.2, 264.3]),         # automatic hops between the listed stations
-    "fft-sea-sick.lua": (128, 128, (128, 128), None, []),                    # no retune handler
-}
+def _lua_traces():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "lua_scene_traces.json")) as fp:
+        return json.load(fp)
+
+
+LUA_SCENES = ("fft.lua", "fft-shifted.lua", "fft-sea.lua", "fft-sea-auto.lua", "fft-sea-sick.lua")
+
+
+def _num(v):
+    return float(v) if isinstance(v, str) else v                      # "inf" / "-inf" / "nan"
+
+
+def _fnv1a(data):
+    h = 1469598103934665603
+    for b in data.tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
 
 
 def _texture_update(L, buf, width, height):
@@ -1378,91 +1388,145 @@ def _texture_update(L, buf, width, height):
     return np.ctypeslib.as_array(c.data.f64, shape=(c.length,))[:size].astype(np.float32)
 
 
-@pytest.mark.parametrize("scene", sorted(SCENES))
-def test_lua_scene_draw_loop_replay(golden, tmp_path, scene, history_mode):
+@pytest.fixture(params=[None, "hann"], ids=["rectangular", "hann"])
+def scene_taper(request, monkeypatch):
+    """NRF_FFT_WINDOW for the scene replays: unset = the reference (the trace's checksums must then be reproduced), "hann" =
+    the same call sequence with the fused taper, against the windowed oracle."""
+    if request.param:
+        monkeypatch.setenv("NRF_FFT_WINDOW", request.param)
+    else:
+        monkeypatch.delenv("NRF_FFT_WINDOW", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("scene", LUA_SCENES)
+def test_lua_scene_trace_replay(golden, tmp_path, scene, history_mode, scene_taper):
     import time
-    n, h, (tw, th), shifter_hz, retunes = SCENES[scene]
+    traces = _lua_traces()
+    events = traces["scenes"][scene]["events"]
     L = nrf.nrf_lib()
-    # a replay file of four blocks: the recorded captures' first 32 KiB (all nrf_fft_process reads for N <= 16384)
+    # the replay file the generator used: four blocks, the recorded captures' first 32 KiB, zero beyond
     blocks = []
-    for key in GOLDEN_KEYS:
+    for key in traces["replay_blocks"]:
         blk = np.zeros(nrf.NRF_BUFFER_SIZE_BYTES, np.uint8)
         blk[: golden[key + "__raw"].size] = golden[key + "__raw"]
         blocks.append(blk)
     path = tmp_path / "replay.raw"
     np.concatenate(blocks).tofile(path)
-    rows = [golden[key + "__mag_%d" % n] for key in GOLDEN_KEYS]          # what each block's row must be
-    fs = 5000000                                                          # the replay device's sample rate (src/nrf.c:254)
+    flipped = [O.flip_u8(b) for b in blocks]
+    fnv = [_fnv1a(f) for f in flipped]
 
-    dev = L.nrf_device_new(97.0, str(path).encode())
-    L.nrf_device_set_paused(dev, 1)
-    shifter = L.nrf_freq_shifter_new(int(shifter_hz), fs) if shifter_hz is not None else None
-    fft = L.nrf_fft_new(n, h)
-    want = np.zeros((h, n))                                               # the history the reference would hold
-    shifted_samples = 0
+    dev = None
+    ffts, shifters, buffers = {}, {}, {}              # trace id -> our objects
+    n_checked = {"get_buffer": 0, "texture": 0, "shift": 0}
 
-    def frame(block_index):
-        nonlocal want, shifted_samples
-        flipped = O.flip_u8(blocks[block_index])
-        deadline = time.time() + 2.0
-        while True:                                                       # the replay thread ingests at 60 Hz
-            samples = L.nrf_device_get_samples_buffer(dev)
-            got = np.ctypeslib.as_array(samples.contents.data.u8, shape=(nrf.NRF_BUFFER_SIZE_BYTES,))
-            if np.array_equal(got, flipped):
-                break
-            L.nut_buffer_free(samples)
-            assert time.time() < deadline, "replay device did not deliver block %d" % block_index
-            time.sleep(0.005)
-        if shifter is not None:
-            L.nrf_freq_shifter_process(shifter, samples)
-            sb = L.nrf_freq_shifter_get_buffer(shifter)
-            L.nrf_fft_process(fft, sb)
-            L.nut_buffer_free(sb)
-            row = O.rows_shifted(flipped[: 2 * n], 1, n, shifter_hz / fs, shifted_samples * (shifter_hz / fs), flip=False)[0]
-            shifted_samples += nrf.NRF_SAMPLES_LENGTH
+    def window_of(n):
+        return O.window(scene_taper, n).astype(np.float32).astype(np.float64) if scene_taper else None
+
+    for ev in events:
+        kind = ev["ev"]
+        if kind == "gc":
+            buf = buffers.pop(ev["buffer"], None)
+            if buf is not None:
+                L.nut_buffer_free(buf["ptr"])
+            continue
+        if kind == "frame":
+            L.nrf_device_step(dev)                    # the tracer's replay device moves one block per rendered frame
+            continue
+        if kind != "call":
+            continue
+        fn = ev["fn"]
+        if fn == "nrf_device_new":
+            assert ev["replayed_blocks"] == len(blocks) and ev["sample_rate"] == 5000000
+            dev = L.nrf_device_new(ev["freq_mhz"], str(path).encode())
+            L.nrf_device_set_paused(dev, 1)
+        elif fn == "nrf_device_set_frequency":
+            assert L.nrf_device_set_frequency(dev, ev["freq_mhz"]) == ev["ret"]
+        elif fn == "nrf_device_get_samples_buffer":
+            want = flipped[ev["block"]]
+            assert fnv[ev["block"]] == ev["ret"]["fnv"], "the replay file is not the generator's"
+            deadline = time.time() + 2.0
+            while True:                               # the replay thread ingests at 60 Hz
+                samples = L.nrf_device_get_samples_buffer(dev)
+                got = np.ctypeslib.as_array(samples.contents.data.u8, shape=(nrf.NRF_BUFFER_SIZE_BYTES,))
+                if np.array_equal(got, want):
+                    break
+                L.nut_buffer_free(samples)
+                assert time.time() < deadline, "replay device did not deliver block %d" % ev["block"]
+                time.sleep(0.005)
+            c = samples.contents
+            assert (c.type, c.length, c.channels) == (ev["ret"]["type"], ev["ret"]["length"], ev["ret"]["channels"])
+            buffers[ev["ret"]["id"]] = {"ptr": samples, "u8": want}
+        elif fn == "nrf_fft_new":
+            n, h = ev["fft_size"], ev["fft_history_size"]
+            ffts[ev["ret"]] = {"ptr": L.nrf_fft_new(n, h), "n": n, "h": h, "want": np.zeros((h, n))}
+        elif fn == "nrf_fft_process":
+            f, b = ffts[ev["fft"]], buffers[ev["buffer"]]
+            L.nrf_fft_process(f["ptr"], b["ptr"])
+            n = f["n"]
+            if "u8" in b:                             # src/nrf.c:603-606 (device buffers are offset binary already)
+                row = (O.rows_windowed(b["u8"][: 2 * n], 1, n, window_of(n), flip=False) if scene_taper
+                       else O.rows(b["u8"][: 2 * n], 1, n, flip=False))[0]
+            else:                                     # src/nrf.c:607-612: the shifter's F64 output
+                row = O.rows_f64(b["f64"][: 2 * n], 1, n, window=window_of(n))[0]
+            f["want"] = np.vstack([row[None, :], f["want"][:-1]])                 # src/nrf.c:616-617: newest row first
+        elif fn == "nrf_fft_shift":
+            f = ffts[ev["fft"]]
+            d = _num(ev["d"])                         # what the binding hands over: (double)(float) of the Lua number
+            assert d == np.float32(_num(ev["d_lua"]))
+            L.nrf_fft_shift(f["ptr"], d)
+            O.fft_shift(f["want"], f["n"], f["h"], d)
+            n_checked["shift"] += 1
+        elif fn == "nrf_fft_get_buffer":
+            f = ffts[ev["fft"]]
+            buf = L.nrf_fft_get_buffer(f["ptr"])
+            c = buf.contents
+            assert (c.type, c.length, c.channels) == (ev["ret"]["type"], ev["ret"]["length"], ev["ret"]["channels"])
+            got = nrf.buffer_to_numpy(L, buf).reshape(f["h"], f["n"])
+            live = np.flatnonzero(f["want"].any(axis=1))
+            if live.size:
+                parity.check_float(got[live], f["want"][live])
+            dead = np.setdiff1d(np.arange(f["h"]), live)
+            assert not got[dead].any()
+            if not scene_taper:                       # the number the reference's own script saw at this point
+                assert abs(float(got.sum()) - _num(ev["ret"]["sum"])) <= 2e-6 * max(1.0, _num(ev["ret"]["abs_sum"]))
+            buffers[ev["ret"]["id"]] = {"ptr": buf, "hist": got}
+            n_checked["get_buffer"] += 1
+        elif fn == "nrf_freq_shifter_new":
+            shifters[ev["ret"]] = {"ptr": L.nrf_freq_shifter_new(ev["freq_offset"], ev["sample_rate"]),
+                                   "args": (ev["freq_offset"], ev["sample_rate"]), "state": (1.0, 0.0), "out": None}
+        elif fn == "nrf_freq_shifter_process":
+            sh, b = shifters[ev["shifter"]], buffers[ev["buffer"]]
+            L.nrf_freq_shifter_process(sh["ptr"], b["ptr"])
+            sh["out"], sh["state"] = O.freq_shift(b["u8"], sh["args"][0], sh["args"][1], sh["state"])
+        elif fn == "nrf_freq_shifter_get_buffer":
+            sh = shifters[ev["shifter"]]
+            buf = L.nrf_freq_shifter_get_buffer(sh["ptr"])
+            c = buf.contents
+            assert (c.type, c.length, c.channels) == (ev["ret"]["type"], ev["ret"]["length"], ev["ret"]["channels"])
+            vals = np.ctypeslib.as_array(c.data.f64, shape=(c.length * c.channels,)).copy()
+            assert np.max(np.abs(vals[: sh["out"].size] - sh["out"])) <= 1e-9 and not vals[sh["out"].size:].any()
+            assert abs(float(vals.sum()) - _num(ev["ret"]["sum"])) <= 1e-6 * _num(ev["ret"]["abs_sum"])
+            buffers[ev["ret"]["id"]] = {"ptr": buf, "f64": vals}
+        elif fn == "ngl_texture_update":
+            b = buffers[ev["buffer"]]
+            tex = _texture_update(L, b["ptr"], ev["width"], ev["height"])
+            if not scene_taper:
+                assert abs(float(tex.sum(dtype=np.float64)) - _num(ev["f32_sum"])) <= 2e-6 * max(1.0, abs(_num(ev["f32_sum"])))
+            with pytest.raises(AssertionError, match="Invalid width / height"):   # the reference's fatal error (src/ngl.c:224-227)
+                _texture_update(L, b["ptr"], ev["width"], ev["height"] + 1)
+            n_checked["texture"] += 1
         else:
-            L.nrf_fft_process(fft, samples)
-            row = rows[block_index]
-        L.nut_buffer_free(samples)
-        want = np.vstack([row[None, :], want[:-1]])                       # src/nrf.c:616-617: newest row first
-        buf = L.nrf_fft_get_buffer(fft)
-        tex = _texture_update(L, buf, tw, th)
-        L.nut_buffer_free(buf)
-        return tex
-
-    def check(tex, exact_rows_from=None):
-        got = tex.reshape(th, tw).astype(np.float64)
-        live = np.flatnonzero(want.any(axis=1))
-        parity.check_float(got[live], want[live].astype(np.float32).astype(np.float64))
-        assert not got[[r for r in range(th) if r not in set(live)]].any()
-        # the checksum a headless run would record for this frame
-        assert abs(float(tex.sum(dtype=np.float64)) - float(want.astype(np.float32).sum(dtype=np.float64))) \
-            <= 2e-6 * max(1.0, float(np.abs(want).sum()))
-
-    k = 0
-    for _ in range(5):                                                    # five rendered frames
-        tex = frame(k % 4)
-        L.nrf_device_step(dev)
-        k += 1
-    check(tex)
-    for d in retunes:                                                     # retune with live rows, then keep drawing
-        L.nrf_device_set_frequency(dev, 97.0 + d)
-        L.nrf_fft_shift(fft, (fs / 1e6) / d)
-        O.fft_shift(want, n, h, (fs / 1e6) / d)
-        for _ in range(2):
-            tex = frame(k % 4)
-            L.nrf_device_step(dev)
-            k += 1
-        check(tex)
-    # a texture larger than the buffer is the reference's fatal error
-    buf = L.nrf_fft_get_buffer(fft)
-    with pytest.raises(AssertionError, match="Invalid width / height"):
-        _texture_update(L, buf, tw, th + 1)
-    L.nut_buffer_free(buf)
-    if shifter is not None:
-        L.nrf_freq_shifter_free(shifter)
+            raise AssertionError("trace names a call the replay does not know: %s" % fn)
+    frames = sum(1 for e in events if e["ev"] == "frame")
+    assert n_checked["get_buffer"] == frames and n_checked["texture"] == frames and n_checked["shift"] >= 1
+    for b in buffers.values():
+        L.nut_buffer_free(b["ptr"])
+    for sh in shifters.values():
+        L.nrf_freq_shifter_free(sh["ptr"])
+    for f in ffts.values():
+        L.nrf_fft_free(f["ptr"])
     L.nrf_device_free(dev)
-    L.nrf_fft_free(fft)
 
 
 def test_launches_can_be_captured_into_a_hip_graph():
