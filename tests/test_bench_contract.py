@@ -145,6 +145,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(roof["frac_by_step_time"] - roof["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9
     assert roof["frac_by_step_time"] <= roof["frac"] * 1.02
     assert d["config"]["clock_prewarm_s"] == 0.25
+    # the secondary ceilings SURVEY 8(d) names, in the line itself: how busy the vector pipes and the LDS are (committed PMC
+    # constants under the same kernel / grid / LDS guard as `traffic`, priced with this run's launch time), and the package
+    # power in the timed steps' own launch shape beside the long launches' (which limit binds where)
+    if roof["traffic"] is not None:
+        assert 0.3 < roof["valu_issue_frac"] < 1.0 and 0.05 < roof["lds_active_frac"] < 1.0
+    if roof.get("package_power_w_in_bench_shape") is not None:
+        assert 300 < roof["package_power_w_in_bench_shape"] <= roof["package_power_w_long_launches"] * 1.05 < 1600
+        assert roof["frac"] * 0.95 < roof["frac_long_launches"] < roof["io_skeleton_frac"] * 1.05 if "io_skeleton_frac" in roof else True
     # the ceilings measured in the same run: the kernel cannot beat its own I/O skeleton, nor that a plain stream
     if "io_skeleton_frac" in roof:
         assert roof["frac"] < roof["io_skeleton_frac"] * 1.05 < roof["copy_frac"] * 1.3 and roof["copy_frac"] < 1.0
