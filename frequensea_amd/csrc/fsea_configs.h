@@ -12,11 +12,11 @@
 #include "fsea_opt.h"
 
 // single-wave frames, no s_barrier; 32 points per lane from 128 points up (dword pass-0 loads)
-#define FSEA_CFG_32 32, 4, 64, 2, 2, 8, 4, 1, 1, true, true, 0, fo::STREAMING_PIXELS
-#define FSEA_CFG_64 64, 4, 64, 2, 2, 16, 4, 1, 1, true, true, 0, fo::STREAMING_PIXELS
-#define FSEA_CFG_128 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, fo::STREAMING_PIXELS
-#define FSEA_CFG_256 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS
-#define FSEA_CFG_512 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS
+#define FSEA_CFG_32 32, 4, 64, 2, 2, 8, 4, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS
+#define FSEA_CFG_64 64, 4, 64, 2, 2, 16, 4, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS
+#define FSEA_CFG_128 128, 4, 64, 2, 2, 16, 8, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS
+#define FSEA_CFG_256 256, 8, 32, 2, 2, 16, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS
+#define FSEA_CFG_512 512, 16, 16, 2, 2, 32, 16, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS
 // 1024 points: round 3 moved from 32 x 32 (2-byte pass-0 loads, one pixel / one f32 bin per lane and store) to 8 x 16 x 8:
 // dwordx2 loads, four adjacent bins per lane in the last pass (dword pixel stores, 16-byte f32 stores), deferred middle-pass
 // twiddles; a second exchange, still no barrier (profiles/r03_1024_three_pass.txt: DB5 / DB10 pixels +6...8 %, f32 rows +1 %)
@@ -25,7 +25,7 @@
 // multi-wave frames: 32 points per lane (4096: two waves per frame, two frames per workgroup), the
 // middle pass's twiddles deferred and register-resident (fo::DEFER)
 #define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::TW_FUSE
 
 // Per-(size, mode) configurations: where the modes of one size prefer different radix orders, a plan takes the one its
@@ -39,12 +39,14 @@
 //       one bin per lane = one 8-byte complex store per row, where the 8 x 16 x 8 of FSEA_CFG_1024 holds four bins per lane,
 //       two 16-byte stores each writing every other 16 bytes of the row: 0.297 against 0.208 ms per 2^27 samples; the f32
 //       rows of that kernel 0.164 against 0.153 ms (the compile-time MAG and pixel kernels prefer 8 x 16 x 8).
-#define FSEA_CFG_256_ROWS 256, 8, 32, 2, 3, 4, 8, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-#define FSEA_CFG_512_PX 512, 16, 16, 2, 2, 16, 32, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::TW_FUSE | fo::BATCH_READS
-#define FSEA_CFG_1024_RT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_256_ROWS 256, 8, 32, 2, 3, 4, 8, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_512_PX 512, 16, 16, 2, 2, 16, 32, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS | fo::LD_NT | fo::TW_FUSE | fo::BATCH_READS
+#define FSEA_CFG_1024_RT 1024, 32, 8, 2, 2, 32, 32, 1, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS | fo::TW_FUSE | fo::BATCH_READS
 
 // Windowed kernels (FftKernel<..., WIN>; fsea_plan_set_window): the lane's P taper weights stay in registers for the
 // workgroup's lifetime at every size (WIN = 2).  Fetching them again for every frame (WIN = 1, the tuning library's "w1"
 // variants) frees 32 registers between pass 0 and the last pass and loses 2-5 % to the extra loads
-// (profiles/r04_window_cost.txt).
+// (profiles/r04_window_cost.txt).  fo::WIN_DC_REGS in a configuration above: the windowed kernels of that size also keep the
+// lane's share of the DC table in registers (round 5: the per-frame LDS read of it cost 2 % of the headline launch,
+// profiles/r05_window_prologue.txt); left out where the 2 CL extra register pairs spill (1024 as 8 x 16 x 8, 2048, 4096, 16384).
 #define FSEA_WIN 2

@@ -601,6 +601,11 @@ struct FftKernel {
     // the row stores instead of behind pass 0 -- with the 32 resident weights on top they would not fit, and this kernel is
     // the NUT_BUFFER_F64 branch of nrf_fft_process (src/nrf.c:607-612): one frame per call, nothing to prefetch
     static constexpr bool LATE_LOAD = WIN != 0 && IN == IN_F32;
+#ifdef FSEA_WIN_ABL  // the measurement-only builds of scripts/r05_window_prologue.sh take the round-4 form apart: DC table through LDS
+    static constexpr bool DC_IN_REGS = false;
+#else
+    static constexpr bool DC_IN_REGS = WIN_DC && (Cfg::OPT & opt::WIN_DC_REGS) != 0;  // see DC_REGS below
+#endif
     static_assert(!RUNS || (IN == IN_U8 && !ROT && Cfg::FPW == 1 && (Cfg::R(0) % 2) == 0), "half-overlap runs: u8 input, one frame per workgroup");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
     static constexpr int LAST = NP - 1;
@@ -1037,8 +1042,13 @@ struct FftKernel {
     // LDS of a kernel in complex units: frames, table block, ticket words, and -- windowed kernels -- the DC term's
     // spectrum for the 2 NsL bins around N/2 (FftArgs::win_dc)
     static constexpr int DC_OFF = (Cfg::LDS_ALLOC + 1) & ~1;  // 16-byte aligned
-    static constexpr int LDS_CF = WIN ? DC_OFF + 2 * NsL : Cfg::LDS_ALLOC;
+    static constexpr int LDS_CF = (WIN_DC && !DC_IN_REGS) ? DC_OFF + 2 * NsL : Cfg::LDS_ALLOC;
     static constexpr int DC_REGS = (2 * NsL + Cfg::WG - 1) / Cfg::WG;
+    // Where a lane's share of the DC table lives.  Its 2 CL values never change from frame to frame; read from LDS per frame
+    // (round 4) they cost two ds_read + a wait right in front of the row stores -- 1.0 of the 2.0 us a Hann taper added to
+    // the 49 us headline launch (profiles/r05_window_prologue.txt, build 3).  Where the register budget has room for them
+    // (opt::WIN_DC_REGS in the size's configuration: every size but 1024 in its 8 x 16 x 8 layout, 2048, 4096 and 16384,
+    // where 2 CL more register pairs spill) they are loaded once, straight from the table, and stay (DC_IN_REGS).
     static_assert(WIN == 0 || (Cfg::TWL || Cfg::TWR), "the DC table rides on the table block's barrier");
     // the lane's P weights, (-1)^n w[n] in the order of its pass-0 registers (FftArgs::win): P/4 16-byte loads, the T
     // lanes' pieces of one load adjacent in memory
@@ -1159,7 +1169,15 @@ struct FftKernel {
         // Requested in front of unit 0's bytes: they come from L2 and must not queue behind the HBM burst of the launch's start.
         [[maybe_unused]] const rsrc_t win_rs = buffer_window(WIN ? a.win : nullptr, 0, WIN ? (size_t)N * 4u : 0);
         cf wv[WPAIRS];
-        cf dcv[WIN_DC ? DC_REGS : 1];
+        cf dcv[(WIN_DC && !DC_IN_REGS) ? DC_REGS : 1];
+        cf dcr[DC_IN_REGS ? 2 * CL : 1];  // this lane's bins of the two last-pass rows around N/2: [c] row RL/2 - 1, [CL + c] row RL/2
+        if constexpr (DC_IN_REGS) {
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                dcr[c] = a.win_dc[CL * tl + c];
+                dcr[CL + c] = a.win_dc[NsL + CL * tl + c];
+            }
+        }
 #ifndef FSEA_WIN_ABL  // measurement-only builds (scripts/r05_window_prologue.sh): 1 = no weight-table loads, 2 = no DC-table loads either, 3 = nor the per-frame DC add
         if constexpr (WIN != 0) load_window(win_rs, t, wv);
 #else
@@ -1168,7 +1186,7 @@ struct FftKernel {
             for (int i = 0; i < WPAIRS; ++i) wv[i] = cf{1.0f + 0.001f * (float)(t & 7), -1.0f};
         }
 #endif
-        if constexpr (WIN_DC) {
+        if constexpr (WIN_DC && !DC_IN_REGS) {
 #pragma unroll
             for (int i = 0; i < DC_REGS; ++i) {
                 const int e = tid + i * Cfg::WG;
@@ -1198,7 +1216,7 @@ struct FftKernel {
                 // lanes past the end rewrite the last entry with its own value (loaded clamped above)
                 lds_all[FPW * Cfg::LDS_FRAME + (e < TAB_COPY ? e : TAB_COPY - 1)] = tabv[i];
             }
-            if constexpr (WIN_DC) {
+            if constexpr (WIN_DC && !DC_IN_REGS) {
 #pragma unroll
                 for (int i = 0; i < DC_REGS; ++i) {
                     const int e = tid + i * Cfg::WG;
@@ -1397,10 +1415,17 @@ struct FftKernel {
 #pragma unroll
                 for (int c = 0; c < CL; ++c) dft_regs<RL, CL, (Cfg::ABL & abl::NO_FLOPS) != 0>(v + c);
             }
+            if constexpr (DC_IN_REGS) {
+#pragma unroll
+                for (int c = 0; c < CL; ++c) {
+                    v[(RL / 2 - 1) * CL + c] += dcr[c];
+                    v[(RL / 2) * CL + c] += dcr[CL + c];
+                }
+            }
 #if defined(FSEA_WIN_ABL) && FSEA_WIN_ABL >= 3
             if constexpr (false) {
 #else
-            if constexpr (WIN_DC) {
+            if constexpr (WIN_DC && !DC_IN_REGS) {
 #endif
                 // the offset-binary DC term's spectrum, for this lane's bins of the two rows around N/2
                 // (two bins at a time: the 2 CL values in flight at once cost spills at 1024 points, CL = 4)

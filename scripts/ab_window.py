@@ -13,7 +13,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 paths = sys.argv[1:] + [os.path.join(ROOT, "frequensea_amd", "libfsea_hip.so")]
 vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
-n, frames, sets = 8192, 4096, 6
+n = int(os.environ.get("AB_N", "8192"))                 # AB_N: another transform size, same 64 MiB of samples per launch
+frames, sets = (1 << 25) // n, 6
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 host = np.random.default_rng(1).integers(-70, 70, 2 * frames * n, dtype=np.int8)
@@ -45,14 +46,19 @@ while time.perf_counter() - t0 < 0.5:
         run(L, p, 32)
     torch.cuda.synchronize()
 res = {name: [] for name, _, _ in plans}
-for rnd in range(15):
+# AB_REGION launches per timed region (default 200); bench.py's informational figures use regions of 20 launches, each
+# started from an idle chip behind a device synchronise -- AB_REGION=20 AB_ROUNDS=60 measures in that form
+REGION = int(os.environ.get("AB_REGION", "200"))
+ROUNDS = int(os.environ.get("AB_ROUNDS", "15"))
+print("N = %d, %d frames per launch; timed regions of %d launches, %d interleaved rounds" % (n, frames, REGION, ROUNDS))
+for rnd in range(ROUNDS):
     for name, L, p in (plans if rnd % 2 == 0 else plans[::-1]):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        run(L, p, 200)
+        run(L, p, REGION)
         e1.record()
         torch.cuda.synchronize()
-        res[name].append(1e3 * e0.elapsed_time(e1) / 200)
+        res[name].append(1e3 * e0.elapsed_time(e1) / REGION)
 for name, _, _ in plans:
     v = np.array(res[name])
     print("%-44s us/launch: median %.2f  min %.2f  max %.2f" % (name, np.median(v), v.min(), v.max()))

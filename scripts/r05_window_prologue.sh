@@ -20,5 +20,8 @@ if [ "$1" = "build" ]; then
   ls -la scripts/ab/libfsea_hip_winabl*.so
 else
   mkdir -p gpurun_out
-  python scripts/ab_window.py scripts/ab/libfsea_hip_winabl1.so scripts/ab/libfsea_hip_winabl2.so scripts/ab/libfsea_hip_winabl3.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05_window_prologue.txt
+  for form in "200 15" "20 60" "200 15" "20 60"; do
+    set -- $form
+    AB_REGION=$1 AB_ROUNDS=$2 python scripts/ab_window.py scripts/ab/libfsea_hip_winabl1.so scripts/ab/libfsea_hip_winabl2.so scripts/ab/libfsea_hip_winabl3.so 2>&1 | grep -v amdgpu.ids
+  done | tee gpurun_out/r05_window_prologue.txt
 fi
