@@ -787,7 +787,12 @@ int fsea_plan_grid(const fsea_plan *p, size_t n_frames, unsigned *grid, unsigned
     if (grid) *grid = grid_for(p, p->entry, p->occ[k], n_frames);
     if (block) *block = (unsigned)p->entry->wg;
     // a plan with a taper launches the *_WIN kernels, whose static LDS carries the DC table on top
-    if (lds_bytes) *lds_bytes = (p->window_form != 0 && p->entry->lds_bytes_win) ? p->entry->lds_bytes_win : p->entry->lds_bytes;
+    if (lds_bytes) {
+        *lds_bytes = p->entry->lds_bytes;
+        if (p->window_form != 0 && p->entry->lds_bytes_win) {
+            *lds_bytes = (k == fsea::K_U8_MAG_WIN || k == fsea::K_U8_MAG_HALF_WIN) ? p->entry->lds_bytes_win : p->entry->lds_bytes_win_other;
+        }
+    }
     return FSEA_OK;
 }
 

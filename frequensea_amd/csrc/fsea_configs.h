@@ -20,13 +20,13 @@
 // 1024 points: round 3 moved from 32 x 32 (2-byte pass-0 loads, one pixel / one f32 bin per lane and store) to 8 x 16 x 8:
 // dwordx2 loads, four adjacent bins per lane in the last pass (dword pixel stores, 16-byte f32 stores), deferred middle-pass
 // twiddles; a second exchange, still no barrier (profiles/r03_1024_three_pass.txt: DB5 / DB10 pixels +6...8 %, f32 rows +1 %)
-#define FSEA_CFG_1024 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-#define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_1024 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS_MAG | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS_MAG | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // multi-wave frames: 32 points per lane (4096: two waves per frame, two frames per workgroup), the
 // middle pass's twiddles deferred and register-resident (fo::DEFER)
 #define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-#define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::TW_FUSE
+#define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS_MAG | fo::LD_NT | fo::DEFER | fo::TW_FUSE
 
 // Per-(size, mode) configurations: where the modes of one size prefer different radix orders, a plan takes the one its
 // mode prefers (fsea_api.hip: preferred_variant; registry variants "rows" / "px" / "rt", full kernel sets).  Measured in one
@@ -48,5 +48,6 @@
 // variants) frees 32 registers between pass 0 and the last pass and loses 2-5 % to the extra loads
 // (profiles/r04_window_cost.txt).  fo::WIN_DC_REGS in a configuration above: the windowed kernels of that size also keep the
 // lane's share of the DC table in registers (round 5: the per-frame LDS read of it cost 2 % of the headline launch,
-// profiles/r05_window_prologue.txt); left out where the 2 CL extra register pairs spill (1024 as 8 x 16 x 8, 2048, 4096, 16384).
+// profiles/r05_window_prologue.txt); fo::WIN_DC_REGS_MAG: only in the compile-time MAG kernels (1024 as 8 x 16 x 8, 2048, 16384: the
+// other kinds spill with the 2 CL extra register pairs); 4096 keeps the LDS form throughout.
 #define FSEA_WIN 2

@@ -604,7 +604,8 @@ struct FftKernel {
 #ifdef FSEA_WIN_ABL  // the measurement-only builds of scripts/r05_window_prologue.sh take the round-4 form apart: DC table through LDS
     static constexpr bool DC_IN_REGS = false;
 #else
-    static constexpr bool DC_IN_REGS = WIN_DC && (Cfg::OPT & opt::WIN_DC_REGS) != 0;  // see DC_REGS below
+    static constexpr bool DC_IN_REGS = WIN_DC && ((Cfg::OPT & opt::WIN_DC_REGS) != 0 ||
+                                                  ((Cfg::OPT & opt::WIN_DC_REGS_MAG) != 0 && MODE_T == MODE_MAG && !ROT));  // see DC_REGS below
 #endif
     static_assert(!RUNS || (IN == IN_U8 && !ROT && Cfg::FPW == 1 && (Cfg::R(0) % 2) == 0), "half-overlap runs: u8 input, one frame per workgroup");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
@@ -1047,8 +1048,9 @@ struct FftKernel {
     // Where a lane's share of the DC table lives.  Its 2 CL values never change from frame to frame; read from LDS per frame
     // (round 4) they cost two ds_read + a wait right in front of the row stores -- 1.0 of the 2.0 us a Hann taper added to
     // the 49 us headline launch (profiles/r05_window_prologue.txt, build 3).  Where the register budget has room for them
-    // (opt::WIN_DC_REGS in the size's configuration: every size but 1024 in its 8 x 16 x 8 layout, 2048, 4096 and 16384,
-    // where 2 CL more register pairs spill) they are loaded once, straight from the table, and stay (DC_IN_REGS).
+    // (opt::WIN_DC_REGS in the size's configuration; opt::WIN_DC_REGS_MAG: its compile-time MAG kernels only, at 1024 in the
+    // 8 x 16 x 8 layout, 2048 and 16384, where the other kinds spill with 2 CL more register pairs; 4096 keeps the LDS form)
+    // they are loaded once, straight from the table, and stay (DC_IN_REGS).
     static_assert(WIN == 0 || (Cfg::TWL || Cfg::TWR), "the DC table rides on the table block's barrier");
     // the lane's P weights, (-1)^n w[n] in the order of its pass-0 registers (FftArgs::win): P/4 16-byte loads, the T
     // lanes' pieces of one load adjacent in memory

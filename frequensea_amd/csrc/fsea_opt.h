@@ -17,6 +17,7 @@ enum : int {
     PX_PACK = 2097152,      // pixel epilogue: v_cvt_pk_u8_f32 converts, clamps and packs
     PX_BIAS = 4194304,      // ... its round-to-nearest biased into the reference's truncation (no v_trunc)
     WIN_DC_REGS = 16777216, // windowed kernels only: the lane's share of the DC table stays in registers (no LDS read per frame)
+    WIN_DC_REGS_MAG = 33554432, // ... in the compile-time MAG kernels only (the nrf_fft_process / STFT path), where the other kinds would spill
     // ---- tuning library only (fsea_fft_tune.h; measured and not adopted) ----
     V2 = 64,                // the two-barrier schedule (FftKernel::run_v2)
     W64 = 1048576,          // 4096 points as 64 x 64 in one wavefront (FftKernel::run_w64)

@@ -30,7 +30,8 @@ struct KernelEntry {
     int t, fpw, wg, np;
     int radix[4];
     size_t lds_bytes;
-    size_t lds_bytes_win;  // static LDS of the *_WIN kernels (the DC table on top); 0 = no windowed kernels
+    size_t lds_bytes_win;  // static LDS of the windowed compile-time MAG kernels (*_u8_mag_win, *_u8_mag_half_win); 0 = no windowed kernels
+    size_t lds_bytes_win_other;  // ... of the other windowed u8 kinds (where the DC table sits in LDS it comes on top)
     int c0;                // samples per pass-0 load (hop must be a multiple)
     int counters;          // ticket counters: 0 = never used (single-wave frames), 1 = by launches with FftArgs::dynamic_units,
                            // 2 = by every launch (the V2 schedule and the progress-word experiments of the tuning library)
@@ -56,7 +57,7 @@ struct KernelEntry {
 #define FSEA_KERNEL_ENTRY_HEAD_(NAME, VARIANT)                                                        \
     NAME##_cfg::N, VARIANT, NAME##_cfg::T, NAME##_cfg::FPW, NAME##_cfg::WG, NAME##_cfg::NP,           \
         {NAME##_cfg::R(0), NAME##_cfg::R(1), NAME##_cfg::R(2), NAME##_cfg::R(3)},                     \
-        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC, 0, NAME##_cfg::C(0),                                 \
+        sizeof(fsea::cf) * NAME##_cfg::LDS_ALLOC, 0, 0, NAME##_cfg::C(0),                                 \
         fsea::FftKernel<NAME##_cfg, fsea::IN_U8>::counters_used()
 
 // Defines the six __global__ entry points of one configuration, with plain C names so that
@@ -179,6 +180,7 @@ struct KernelEntry {
         e.name[fsea::K_U8_ROT_WIN] = #NAME "_u8_rot_win";                                             \
         e.name[fsea::K_F32_WIN] = #NAME "_f32_win";                                                   \
         e.lds_bytes_win = sizeof(fsea::cf) * fsea::FftKernel<NAME##_cfg, fsea::IN_U8, fsea::MODE_MAG, false, false, WMODE>::LDS_CF; \
+        e.lds_bytes_win_other = sizeof(fsea::cf) * fsea::FftKernel<NAME##_cfg, fsea::IN_U8, -1, false, false, WMODE>::LDS_CF; \
         e.fn[fsea::K_U8_MAG_WIN] = reinterpret_cast<const void *>(&NAME##_u8_mag_win);                \
         e.fn[fsea::K_U8_DB5_WIN] = reinterpret_cast<const void *>(&NAME##_u8_db5_win);                \
         e.fn[fsea::K_U8_DB10_WIN] = reinterpret_cast<const void *>(&NAME##_u8_db10_win);              \

@@ -9,6 +9,8 @@
 #   2. bench.py at 1, 2, 4 ... N ranks: the headline (frames sharded, no collective), the fft-batch-broad sweep with
 #      resident and with ingested captures (its chunks alternate on two streams per rank), the halo-sharded 16384-point
 #      stream, rectangular and with the fused Hann taper -- every line carries its regime and window in `config`
+#   3. the driver's own line, `bench.py --gpus n --steps 20 --warmup 5`, at 1, 2, 4 ... N ranks: headline + the multi-GPU leg in
+#      `extra` (census, checksums of what arrived, gather rate) -- what the round-end SCALE record will contain
 # Every step runs under `timeout`; nothing can hang the node.
 # Usage: bash scripts/multi_gpu_check.sh [N] [--dry-run] [--log FILE]
 #   --dry-run   print the commands instead of running them (no GPU needed; tests/test_host_api.py checks the plumbing)
@@ -150,6 +152,39 @@ else:
 PY
     fi
   done
+  n=$((n * 2))
+done
+# ---- 3. the driver's OWN command line: bench.py --gpus n --steps 20 --warmup 5 (what SCALE_rNN.json is made from) --------------
+# Since round 5 this one line runs, behind the headline's timed steps, the sharded sweep in both regimes and the halo-sharded
+# stream with the chunked RCCL gather, and reports the communicator's census, the checksums of what arrived against what the
+# members computed and the gather's rate per link in `extra` (bench.py: multi_gpu_leg).  The checksums must be the same at every n.
+n=1
+while [ $n -le "$N" ]; do
+  port=$((port + 1))
+  if [ $n -eq 1 ]; then
+    run "driver line x1" python bench.py --gpus 1 --steps 20 --warmup 5
+  else
+    run "driver line x$n" python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py --gpus $n --steps 20 --warmup 5
+  fi
+  if [ $DRY = 0 ]; then
+    python - "$LOG.step" "$n" <<'PY' 2>&1 | tee -a "$LOG"
+import sys, json
+lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
+if not lines:
+    print("RESULT[driver line x%s]: no JSON line" % sys.argv[2])
+else:
+    d = json.loads(lines[-1]); e = d.get("extra", {})
+    print("RESULT[driver line x%s]: value %.4g frames/s (weak), multi_gpu_error %s, backend %s, rccl_world %s, distinct GPUs %s" %
+          (sys.argv[2], d["value"], e.get("multi_gpu_error"), e.get("gather_backend"), e.get("rccl_world"), e.get("distinct_gpus")))
+    print("RESULT[driver line x%s]: sweep resident %.3f ms, ingest %.3f ms, stream %.3f ms; gather alone %s ms = %s GB/s per link, %s GB/s into the root" %
+          (sys.argv[2], e.get("broad_sweep_ms_resident", float("nan")), e.get("broad_sweep_ms_ingest", float("nan")), e.get("stft_stream_ms", float("nan")),
+           e.get("gather_only_ms"), e.get("gather_gbps_per_link"), e.get("gather_gbps_into_root")))
+    print("RESULT[driver line x%s]: checksums sweep %s / %s (ok %s / %s), stream %s (ok %s)" %
+          (sys.argv[2], e.get("broad_sweep_resident_gathered_checksum"), e.get("broad_sweep_ingest_gathered_checksum"),
+           e.get("broad_sweep_resident_gathered_checksum_ok"), e.get("broad_sweep_ingest_gathered_checksum_ok"),
+           e.get("stft_stream_gathered_checksum"), e.get("stft_stream_gathered_checksum_ok")))
+PY
+  fi
   n=$((n * 2))
 done
 [ $DRY = 0 ] && rm -rf "$W" "$LOG.step"
