@@ -238,7 +238,7 @@ while time.time() < t_end:
     plan = plans[key]
     plan.set_unit_distribution(int(rng.integers(3)))
     tiled, shape, shift = False, None, None
-    if rng.random() < 0.12 and not anysize and not wname:        # the frequency shifter fused into the load (fsea_exec_u8_shifted_device)
+    if rng.random() < 0.12 and not anysize:        # the frequency shifter fused into the load (fsea_exec_u8_shifted_device); with a taper: *_u8_rot_win
         shift = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0, 1)))
         plan.exec_shifted_device(ctypes.c_void_p(d_in.value + off), nf, d_out[si], shift[0], shift[1], flip=flip,
                                  stream=streams[si].value)
