@@ -601,12 +601,8 @@ struct FftKernel {
     // the row stores instead of behind pass 0 -- with the 32 resident weights on top they would not fit, and this kernel is
     // the NUT_BUFFER_F64 branch of nrf_fft_process (src/nrf.c:607-612): one frame per call, nothing to prefetch
     static constexpr bool LATE_LOAD = WIN != 0 && IN == IN_F32;
-#ifdef FSEA_WIN_ABL  // the measurement-only builds of scripts/r05_window_prologue.sh take the round-4 form apart: DC table through LDS
-    static constexpr bool DC_IN_REGS = false;
-#else
     static constexpr bool DC_IN_REGS = WIN_DC && ((Cfg::OPT & opt::WIN_DC_REGS) != 0 ||
                                                   ((Cfg::OPT & opt::WIN_DC_REGS_MAG) != 0 && MODE_T == MODE_MAG && !ROT));  // see DC_REGS below
-#endif
     static_assert(!RUNS || (IN == IN_U8 && !ROT && Cfg::FPW == 1 && (Cfg::R(0) % 2) == 0), "half-overlap runs: u8 input, one frame per workgroup");
     static constexpr int N = Cfg::N, T = Cfg::T, P = Cfg::P, NP = Cfg::NP, FPW = Cfg::FPW;
     static constexpr int LAST = NP - 1;
@@ -1180,24 +1176,12 @@ struct FftKernel {
                 dcr[CL + c] = a.win_dc[NsL + CL * tl + c];
             }
         }
-#ifndef FSEA_WIN_ABL  // measurement-only builds (scripts/r05_window_prologue.sh): 1 = no weight-table loads, 2 = no DC-table loads either, 3 = nor the per-frame DC add
         if constexpr (WIN != 0) load_window(win_rs, t, wv);
-#else
-        if constexpr (WIN != 0) {
-#pragma unroll
-            for (int i = 0; i < WPAIRS; ++i) wv[i] = cf{1.0f + 0.001f * (float)(t & 7), -1.0f};
-        }
-#endif
         if constexpr (WIN_DC && !DC_IN_REGS) {
 #pragma unroll
             for (int i = 0; i < DC_REGS; ++i) {
                 const int e = tid + i * Cfg::WG;
-#if defined(FSEA_WIN_ABL) && FSEA_WIN_ABL >= 2
-                dcv[i] = cf{0.0f, 0.0f};
-                (void)e;
-#else
                 dcv[i] = a.win_dc[e < 2 * NsL ? e : 2 * NsL - 1];  // clamped, as the table block above
-#endif
             }
         }
         Raw raw[R0];
@@ -1424,11 +1408,7 @@ struct FftKernel {
                     v[(RL / 2) * CL + c] += dcr[CL + c];
                 }
             }
-#if defined(FSEA_WIN_ABL) && FSEA_WIN_ABL >= 3
-            if constexpr (false) {
-#else
             if constexpr (WIN_DC && !DC_IN_REGS) {
-#endif
                 // the offset-binary DC term's spectrum, for this lane's bins of the two rows around N/2
                 // (two bins at a time: the 2 CL values in flight at once cost spills at 1024 points, CL = 4)
                 constexpr int CB = CL >= 2 ? 2 : 1;

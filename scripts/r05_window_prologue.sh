@@ -8,6 +8,9 @@
 #   FSEA_WIN_ABL=3  ... and the per-frame DC add (two LDS reads, two packed adds per lane-frame) is left out
 # run beside the product library in ONE process (scripts/ab_window.py: interleaved rounds after a common pre-warm).
 # An in-prologue computation of cosine-sum weights can at best reach build 1's time.
+# The -DFSEA_WIN_ABL hooks these builds need lived in fsea_fft_core.h from commit 1b31553 to 347805d and were taken out of the
+# product header again once the measurement was recorded (profiles/r05_window_prologue.txt): check one of those commits out to
+# repeat it.
 # Usage: bash scripts/r05_window_prologue.sh build   (in the build container: cross-compiles the three libraries)
 #        bash scripts/r05_window_prologue.sh run     (on the GPU box)
 R=$(cd "$(dirname "$0")/.." && pwd)
