@@ -1206,15 +1206,17 @@ def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
     import traceback
     stage = ["starting"]
 
+    limit = [float(args.multi_gpu_timeout)]
+
     def on_timeout():
-        msg = "the multi-GPU leg did not finish within %.0f s (stage: %s); line printed without it" % (args.multi_gpu_timeout, stage[0])
+        msg = "the multi-GPU leg did not finish within %.0f s (stage: %s); line printed without it" % (limit[0], stage[0])
         line.setdefault("extra", {})["multi_gpu_error"] = msg
         print("bench.py rank %d: %s" % (rank, msg), file=sys.stderr)
         emit_line(line, rank)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
-    dog = threading.Timer(args.multi_gpu_timeout, on_timeout)
+    dog = threading.Timer(limit[0], on_timeout)
     dog.daemon = True
     dog.start()
     flat, lines = {}, {}
@@ -1230,8 +1232,8 @@ def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
     dog.cancel()
     if dist is not None and not _LEG_FAILED[0]:
         # did every rank get through?  (a rank that failed is not here: a short watchdog then ends the wait)
-        args.multi_gpu_timeout, stage[0] = 45.0, "closing census (a peer left the leg early: see its stderr)"
-        dog = threading.Timer(45.0, on_timeout)
+        limit[0], stage[0] = 45.0, "closing census (a peer left the leg early: see its stderr)"
+        dog = threading.Timer(limit[0], on_timeout)
         dog.daemon = True
         dog.start()
         try:
