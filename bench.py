@@ -833,7 +833,7 @@ def cpu_baseline(n, hop, cores, budget_s, nrf_stream=False):
     return out
 
 
-def multi_gpu_leg(args, rank, world, dist, torch, stage):
+def multi_gpu_leg(args, rank, world, dist, torch, stage, flat=None):
     """The two BASELINE workloads that have a real exchange step, in the form north_star scales them, run by the SAME
     command line the driver uses for its scaling record (`bench.py --gpus N`), after the headline's timed steps:
 
@@ -844,11 +844,13 @@ def multi_gpu_leg(args, rank, world, dist, torch, stage):
       config 5  one 16384-point 50 %-overlap stream, frame ranges with a redundantly read halo, f32 rows gathered to rank 0.
 
     Both are strong-scaling figures (the job is fixed, a step is the whole job including gather and stitch) and live in
-    `extra`; `value` stays the headline's.  `stage` (a one-element list) names what is running, for the watchdog's message.
+    `extra`; `value` stays the headline's.  `stage` (a one-element list) names what is running, for the watchdog's message;
+    `flat` is filled in place stage by stage, so that a leg that hangs half-way still reports the stages it finished.
     Returns (flat keys for `extra`, {name: full line} for `extra.multi_gpu_lines`)."""
     import copy
     backend = dist.get_backend() if dist is not None else None
-    flat = {"gather_backend": backend if backend else "none (one rank, nothing to gather)", "gather_chunks": None}
+    flat = {} if flat is None else flat                      # filled in place: what is in it when the watchdog fires is printed
+    flat.update({"gather_backend": backend if backend else "none (one rank, nothing to gather)", "gather_chunks": None})
     lines = {}
     stage[0] = "communicator census"
     # what the communicator itself reports: a SUM of ones over its ranks, on the device under nccl (an RCCL all-reduce)
@@ -1207,10 +1209,12 @@ def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
     stage = ["starting"]
 
     limit = [float(args.multi_gpu_timeout)]
+    partial = {}
 
     def on_timeout():
         msg = "the multi-GPU leg did not finish within %.0f s (stage: %s); line printed without it" % (limit[0], stage[0])
-        line.setdefault("extra", {})["multi_gpu_error"] = msg
+        line.setdefault("extra", {}).update(dict(partial))   # the stages that did finish
+        line["extra"]["multi_gpu_error"] = msg
         print("bench.py rank %d: %s" % (rank, msg), file=sys.stderr)
         emit_line(line, rank)
         sys.stdout.flush()
@@ -1219,15 +1223,16 @@ def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
     dog = threading.Timer(limit[0], on_timeout)
     dog.daemon = True
     dog.start()
-    flat, lines = {}, {}
+    flat, lines = partial, {}
     try:
-        flat, lines = multi_gpu_leg(args, rank, world, dist, torch, stage)
+        flat, lines = multi_gpu_leg(args, rank, world, dist, torch, stage, flat=partial)
         flat["multi_gpu_error"] = None
     except BaseException as e:                                   # SystemExit from the leg's own checks included
         if isinstance(e, KeyboardInterrupt):
             raise
         _LEG_FAILED[0] = True
-        flat = {"multi_gpu_error": "rank %d, stage %s: %s: %s" % (rank, stage[0], type(e).__name__, e)}
+        flat = dict(partial)                                     # the stages that did finish stay in the line
+        flat["multi_gpu_error"] = "rank %d, stage %s: %s: %s" % (rank, stage[0], type(e).__name__, e)
         print("bench.py rank %d: multi-GPU leg failed in stage %s\n%s" % (rank, stage[0], traceback.format_exc()), file=sys.stderr)
     dog.cancel()
     if dist is not None and not _LEG_FAILED[0]:

@@ -34,13 +34,15 @@ import argparse, json, sys, time
 sys.path.insert(0, %r)
 import bench
 mode = sys.argv[1]
-def leg(args, rank, world, dist, torch, stage):
+def leg(args, rank, world, dist, torch, stage, flat=None):
+    flat["gather_backend"] = "nccl"                  # a stage that finished before the trouble
     stage[0] = "broad sweep, resident regime"
     if mode == "raise":
         raise SystemExit("bench broad: the gathered tiles of rank(s) [1] differ")
     if mode == "hang":
         time.sleep(60)
-    return {"rccl_world": 1}, {}
+    flat["rccl_world"] = 1
+    return flat, {}
 bench.multi_gpu_leg = leg
 args = argparse.Namespace(multi_gpu_timeout=1.0)
 line = {"metric": "fft_frames_per_sec_n8192", "value": 123.0}
@@ -62,6 +64,7 @@ def test_the_multi_gpu_leg_can_fail_or_hang_without_costing_the_line(mode):
     d = json.loads(lines[0])
     assert d["value"] == 123.0
     err = d["extra"]["multi_gpu_error"]
+    assert d["extra"]["gather_backend"] == "nccl"     # what the leg had finished is in the line either way
     if mode == "ok":
         assert err is None and d["extra"]["rccl_world"] == 1
     elif mode == "raise":
