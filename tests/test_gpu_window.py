@@ -183,6 +183,28 @@ def test_config5_stft_with_hann_at_full_size():
     plan.close()
 
 
+@pytest.mark.parametrize("mode", [fsea.MODE_MAG_F32, fsea.MODE_DB5_U8_DCFIX])
+def test_windowed_headline_batch_every_row(mode):
+    """BASELINE config 3's batch (8192 points x 4096 frames) with a Hann taper, f32 rows and DB5 pixels: every row against the
+    windowed oracle (frames sharded over the host's cores)."""
+    n, nf = 8192, 4096
+    iq = synth_iq(3, 2 * nf * n)
+    w = fsea.window("hann", n)
+    plan = fsea.Plan(n, mode=mode)
+    plan.set_window(w)
+    d_in = DeviceBuffer(iq.nbytes).upload(iq)
+    d_out = DeviceBuffer(nf * n * (4 if mode == fsea.MODE_MAG_F32 else 1))
+    plan.exec_device(d_in.ptr, nf, d_out.ptr)
+    plan.synchronize()
+    got = d_out.download(np.float32 if mode == fsea.MODE_MAG_F32 else np.uint8, (nf, n))
+    want = O.rows_mt(iq, nf, n, mode=parity.ORACLE_MODE[mode], window=np.asarray(w, np.float32).astype(np.float64))
+    for f0 in range(0, nf, 256):
+        (parity.check_float if mode == fsea.MODE_MAG_F32 else parity.check_u8)(got[f0:f0 + 256], want[f0:f0 + 256])
+    d_in.free()
+    d_out.free()
+    plan.close()
+
+
 @pytest.mark.parametrize("n", [1024, 4096, 8192])
 def test_windowed_long_launches_both_unit_distributions(n, units_policy):  # noqa: F811
     nf = 4096 if n >= 4096 else 8192

@@ -306,3 +306,36 @@ def test_oracle_fft_against_an_fftw3_api_library(golden, n):
     assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
     if n in GOLDEN_SIZES:
         assert np.abs(got[0] - golden["rf_100p900_1__mag_%d" % n]).max() <= 1e-9 * np.abs(want).max()
+
+
+def test_threaded_rows_are_the_single_threaded_rows():
+    """orc_rows_mt (the full-size comparisons of the GPU tier) cuts the frames into contiguous ranges, one pthread each running
+    the single-threaded function: the same rows bit for bit, every mode, with and without a taper, ragged thread counts."""
+    n, nf, hop = 256, 37, 128
+    iq = np.random.default_rng(9).integers(0, 256, 2 * ((nf - 1) * hop + n), dtype=np.uint8)
+    w = O.window("blackman", n)
+    for mode in (O.MODE_MAG, O.MODE_DB10_U8, O.MODE_DB5_U8_DCFIX, O.MODE_COMPLEX, O.MODE_MAG_NODC, O.MODE_DB_F64):
+        for flip in (True, False):
+            want = O.rows(iq, nf, n, hop=hop, flip=flip, mode=mode)
+            for threads in (1, 3, 8, 64):
+                assert np.array_equal(O.rows_mt(iq, nf, n, hop=hop, flip=flip, mode=mode, threads=threads), want), (mode, flip, threads)
+        want = O.rows_windowed(iq, nf, n, w, hop=hop, mode=mode)
+        assert np.array_equal(O.rows_mt(iq, nf, n, hop=hop, mode=mode, window=w, threads=5), want), mode
+    assert O.rows_mt(iq, 0, n, hop=hop).shape == (0, n)
+    assert 1 <= O.host_threads() <= 32
+
+
+def test_windowed_shifted_and_f64_rows_reduce_to_their_unwindowed_forms():
+    n, nf = 128, 6
+    rng = np.random.default_rng(4)
+    iq = rng.integers(0, 256, 2 * n * nf, dtype=np.uint8)
+    ones = np.ones(n)
+    for mode in (O.MODE_MAG, O.MODE_COMPLEX, O.MODE_DB5_U8_DCFIX):
+        assert np.array_equal(O.rows_shifted_windowed(iq, nf, n, 0.013, ones, 0.4, mode=mode), O.rows_shifted(iq, nf, n, 0.013, 0.4, mode=mode))
+    x = rng.normal(0.2, 0.3, 2 * n * nf)
+    plain = np.stack([O.mag_row(O.fft_forward(O.unpack_center_f64(x[2 * f * n: 2 * (f + 1) * n]))) for f in range(nf)])
+    assert np.array_equal(O.rows_f64(x, nf, n), plain) and np.array_equal(O.rows_f64(x, nf, n, window=ones), plain)
+    # the taper sits beside the (-1)^n: against numpy
+    w = O.window("hann", n)
+    z = (x[0::2] + 1j * x[1::2]).reshape(nf, n) * ((-1.0) ** np.arange(n)) * w
+    assert np.max(np.abs(O.rows_f64(x, nf, n, mode=O.MODE_COMPLEX, window=w) - np.fft.fft(z, axis=1))) < 1e-10
