@@ -1061,6 +1061,32 @@ struct FftKernel {
     }
     // pass 0's conversion for the windowed kernels: the byte values as they are (centred, or offset-binary), no (-1)^n --
     // weight and sign are applied by the first butterfly level (pass0_windowed)
+    // The frame loop is software-pipelined: frame k+1's bytes are requested behind frame k's pass 0 and its row stores are issued
+    // behind them, so at the top of an iteration the wave has [loads of this frame, stores of the previous one] in flight, in
+    // that order, and needs only the loads.  gfx950 counts both in vmcnt (they retire in order), and the compiler merges the
+    // loop header's two predecessors by aligning their most recent operations: coming from the prologue there are the loads
+    // alone, so it concludes "at most L - 1 operations may be outstanding" -- and in the steady state that wait also covers
+    // EVERY ROW STORE OF THE PREVIOUS FRAME (s_waitcnt vmcnt(15) ... vmcnt(0) where vmcnt(47) ... vmcnt(32) would do): a frame
+    // starts only after the previous frame's stores have been acknowledged.  With opt::BALANCE_PX / BALANCE_MAG the prologue
+    // issues as many stores as an iteration does, through a zero-sized buffer window (the range check drops them: no traffic),
+    // so that both predecessors present the same profile and the compiler's own count leaves the stores out of the wait.
+    // Worth 2-6 % on the compile-time pixel kernels at every size (byte stores are acknowledged late) and 2-3 % on long
+    // launches of the MAG kernels at 1024 and 8192 points; nothing on the run-time-mode kernels, and the windowed kernels'
+    // longer prologue loses it again (profiles/r05_prologue_stores.txt) -- hence per mode and per configuration.
+    static constexpr bool BALANCE = WIN == 0 && !LATE_LOAD && !RUNS && !ROT && IN == IN_U8 &&
+                                    (((MODE_T == MODE_DB5_U8_DCFIX || MODE_T == MODE_DB10_U8) && (Cfg::OPT & opt::BALANCE_PX) != 0) ||
+                                     (MODE_T == MODE_MAG && (Cfg::OPT & opt::BALANCE_MAG) != 0));
+    static constexpr int BALANCE_STORES = 32;
+    static __device__ __forceinline__ void balance_vmcnt() {
+        if constexpr (BALANCE) {
+            const rsrc_t nowhere = buffer_window(nullptr, 0, 0);
+#pragma unroll
+            for (int i = 0; i < BALANCE_STORES; ++i) {
+                // distinct, non-adjacent offsets: identical stores would be eliminated, adjacent ones merged into wider ones
+                __builtin_amdgcn_raw_buffer_store_b32(0u, nowhere, (uint32_t)(64 * i), 0u, 0);
+            }
+        }
+    }
     template <bool OFFSET>
     static __device__ __forceinline__ void convert_windowed(const Raw *raw, uint32_t xormask, int t, cf *v) {
 #pragma unroll
@@ -1186,6 +1212,7 @@ struct FftKernel {
         }
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (RUNS ? fcur : u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+        balance_vmcnt();
         if (dyn) {
             if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
         }
@@ -1274,6 +1301,7 @@ struct FftKernel {
             __syncthreads();
             u = (nu == NO_UNIT) ? n_units : (size_t)nu;
             load_raw(buffer_window(a.in, (size_t)IN_BPS * (u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
+            balance_vmcnt();
         }
 
         unsigned iter = 0;

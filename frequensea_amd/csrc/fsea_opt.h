@@ -17,6 +17,9 @@ enum : int {
     PX_PACK = 2097152,      // pixel epilogue: v_cvt_pk_u8_f32 converts, clamps and packs
     PX_BIAS = 4194304,      // ... its round-to-nearest biased into the reference's truncation (no v_trunc)
     WIN_DC_REGS = 16777216, // windowed kernels only: the lane's share of the DC table stays in registers (no LDS read per frame)
+    BALANCE_PX = 67108864,  // compile-time pixel kernels: the prologue issues an iteration's worth of stores into a zero-sized window, so
+                            // that the frame loop's vmcnt waits leave the previous frame's row stores out (FftKernel::balance_vmcnt)
+    BALANCE_MAG = 134217728, // the same in the compile-time MAG kernel
     WIN_DC_REGS_MAG = 33554432, // ... in the compile-time MAG kernels only (the nrf_fft_process / STFT path), where the other kinds would spill
     // ---- tuning library only (fsea_fft_tune.h; measured and not adopted) ----
     V2 = 64,                // the two-barrier schedule (FftKernel::run_v2)
@@ -24,7 +27,7 @@ enum : int {
     PW = 8388608,           // last butterfly level in power form (dft_regs_tw_pw)
     TUNE_ONLY = V2 | W64 | PW,
     // the options every product configuration shares
-    STREAMING_PIXELS = ST_NT | PX_PACK | PX_BIAS,
+    STREAMING_PIXELS = ST_NT | PX_PACK | PX_BIAS | BALANCE_PX,
 };
 }  // namespace opt
 namespace abl {  // measurement-only ablations (wrong results by design); always 0 in a product configuration
