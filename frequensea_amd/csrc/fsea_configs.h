@@ -6,8 +6,8 @@
 // that its round-to-nearest gives the reference's truncation (fo::PX_PACK | fo::PX_BIAS: two VALU ops per pixel fewer than cast
 // + clamp + shift/or; profiles/r03_w64_and_pixel_epilogue.txt: +2 % at 8192 points, +4 % at 4096, +5.5 % at 256): together
 // fo::STREAMING_PIXELS, which since round 5 also carries fo::BALANCE_PX (the pixel kernels' frame loop does not wait for the
-// previous frame's row stores: FftKernel::balance_vmcnt, +2...6 % at every size; fo::BALANCE_MAG: the same in the MAG kernels of
-// the two sizes of the metric, +2...3 % on long launches).  fo::LD_NT: the input bytes streamed as well -- sizes whose pass-0 loads are at least a dword per lane
+// previous frame's row stores: FftKernel::balance_vmcnt, +2...6 % at every size; fo::BALANCE_MAG: the same in the MAG kernels at
+// 1024 ... 8192 points, +2...4 % on long launches; no effect at 16384, none or negative at 512 and below).  fo::LD_NT: the input bytes streamed as well -- sizes whose pass-0 loads are at least a dword per lane
 // (profiles/r02_tune_nt_*).
 #pragma once
 
@@ -23,10 +23,10 @@
 // dwordx2 loads, four adjacent bins per lane in the last pass (dword pixel stores, 16-byte f32 stores), deferred middle-pass
 // twiddles; a second exchange, still no barrier (profiles/r03_1024_three_pass.txt: DB5 / DB10 pixels +6...8 %, f32 rows +1 %)
 #define FSEA_CFG_1024 1024, 32, 8, 2, 3, 8, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::BALANCE_MAG | fo::WIN_DC_REGS_MAG | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
-#define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS_MAG | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_2048 2048, 64, 4, 2, 3, 16, 16, 8, 1, true, true, 0, fo::STREAMING_PIXELS | fo::BALANCE_MAG | fo::WIN_DC_REGS_MAG | fo::LD_NT | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 // multi-wave frames: 32 points per lane (4096: two waves per frame, two frames per workgroup), the
 // middle pass's twiddles deferred and register-resident (fo::DEFER)
-#define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::LD_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
+#define FSEA_CFG_4096 4096, 128, 2, 2, 3, 16, 16, 16, 1, true, true, 0, fo::STREAMING_PIXELS | fo::BALANCE_MAG | fo::LD_NT | fo::DEFER | fo::LANE_ROT_LAST | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_8192 8192, 256, 1, 2, 3, 16, 16, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::BALANCE_MAG | fo::WIN_DC_REGS | fo::LD_NT | fo::DEFER | fo::LANE_ROT | fo::TW_FUSE | fo::TW_HOIST | fo::BATCH_READS
 #define FSEA_CFG_16384 16384, 512, 1, 2, 3, 16, 32, 32, 1, true, true, 0, fo::STREAMING_PIXELS | fo::WIN_DC_REGS_MAG | fo::LD_NT | fo::DEFER | fo::TW_FUSE
 

@@ -1070,10 +1070,11 @@ struct FftKernel {
     // starts only after the previous frame's stores have been acknowledged.  With opt::BALANCE_PX / BALANCE_MAG the prologue
     // issues as many stores as an iteration does, through a zero-sized buffer window (the range check drops them: no traffic),
     // so that both predecessors present the same profile and the compiler's own count leaves the stores out of the wait.
-    // Worth 2-6 % on the compile-time pixel kernels at every size (byte stores are acknowledged late) and 2-3 % on long
-    // launches of the MAG kernels at 1024 and 8192 points; nothing on the run-time-mode kernels, and the windowed kernels'
-    // longer prologue loses it again (profiles/r05_prologue_stores.txt) -- hence per mode and per configuration.
-    static constexpr bool BALANCE = WIN == 0 && !LATE_LOAD && !RUNS && !ROT && IN == IN_U8 &&
+    // Worth 2-7 % on the compile-time pixel kernels at every size (byte stores are acknowledged late) and 2-4 % on long
+    // launches of the MAG kernels at 1024 ... 8192 points (1 % in the half-overlap form); nothing at 16384 points or on the
+    // run-time-mode kernels, and the windowed kernels' longer prologue loses it again (profiles/r05_prologue_stores.txt) --
+    // hence per mode and per configuration.
+    static constexpr bool BALANCE = WIN == 0 && !LATE_LOAD && !ROT && IN == IN_U8 &&
                                     (((MODE_T == MODE_DB5_U8_DCFIX || MODE_T == MODE_DB10_U8) && (Cfg::OPT & opt::BALANCE_PX) != 0) ||
                                      (MODE_T == MODE_MAG && (Cfg::OPT & opt::BALANCE_MAG) != 0));
     static constexpr int BALANCE_STORES = 32;

@@ -14,10 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 paths = sys.argv[1:] + [os.path.join(ROOT, "frequensea_amd", "libfsea_hip.so")]
 vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 n = int(os.environ.get("AB_N", "8192"))                 # AB_N: another transform size, same 64 MiB of samples per launch
-frames, sets = (1 << 25) // n, 6
+hop = int(os.environ.get("AB_HOP", str(n)))             # AB_HOP = n / 2: BASELINE config 5's overlapped frames
+frames, sets = (1 << 25) // hop - (1 if hop < n else 0), 6
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-host = np.random.default_rng(1).integers(-70, 70, 2 * frames * n, dtype=np.int8)
+host = np.random.default_rng(1).integers(-70, 70, 2 * ((frames - 1) * hop + n), dtype=np.int8)
 ins = [torch.from_numpy(np.roll(host, 16 * s)).to(dev) for s in range(sets)]
 outs = [torch.empty(frames * n, dtype=torch.float32, device=dev) for _ in range(sets)]
 w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)).astype(np.float32)
@@ -29,7 +30,7 @@ for path in paths:
     L.fsea_plan_set_window.argtypes = [vp, vp]
     for tag in ("rect", "hann"):
         p = vp()
-        assert L.fsea_plan_create(ctypes.byref(p), n, n, 0, 0) == 0
+        assert L.fsea_plan_create(ctypes.byref(p), n, hop, 0, 0) == 0
         if tag == "hann":
             assert L.fsea_plan_set_window(p, w.ctypes.data) == 0
         plans.append((os.path.basename(path) + ":" + tag, L, p))
@@ -50,7 +51,7 @@ res = {name: [] for name, _, _ in plans}
 # started from an idle chip behind a device synchronise -- AB_REGION=20 AB_ROUNDS=60 measures in that form
 REGION = int(os.environ.get("AB_REGION", "200"))
 ROUNDS = int(os.environ.get("AB_ROUNDS", "15"))
-print("N = %d, %d frames per launch; timed regions of %d launches, %d interleaved rounds" % (n, frames, REGION, ROUNDS))
+print("N = %d, hop %d, %d frames per launch; timed regions of %d launches, %d interleaved rounds" % (n, hop, frames, REGION, ROUNDS))
 for rnd in range(ROUNDS):
     for name, L, p in (plans if rnd % 2 == 0 else plans[::-1]):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
