@@ -1211,12 +1211,16 @@ struct FftKernel {
                 dcv[i] = a.win_dc[e < 2 * NsL ? e : 2 * NsL - 1];  // clamped, as the table block above
             }
         }
+        // the ticket for the second unit goes out IN FRONT of unit 0's bytes: in the loop the ticket request is older than the
+        // frame's loads and stores, and the prologue has to present the same order, or the compiler's merged wait for the
+        // ticket (issuer wave, top of every iteration of a long launch) is vmcnt(0) -- all row stores of the previous frame
+        // acknowledged -- where the ticket alone would do (balance_vmcnt above)
+        if (dyn) {
+            if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);
+        }
         Raw raw[R0];
         load_raw(buffer_window(a.in, (size_t)IN_BPS * (RUNS ? fcur : u * FPW) * a.hop, u < n_units ? total_in : 0), in_voff, raw);
         balance_vmcnt();
-        if (dyn) {
-            if (issuer) tick_next = atomicAdd(a.ctr + 32 * cur, 1u);  // ticket for the second unit
-        }
 
         // The small twiddle block (middle-pass tables + HI/LO factors, a few KiB) goes to LDS, and
         // the last pass's register-resident twiddles W^{r k}, k = CL t + c, are built from the
