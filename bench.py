@@ -1086,10 +1086,12 @@ def main():
                               "two_stream_frames_per_sec_n1024": ex["two_stream"]})
         # the taper window north_star names, fused into pass 0 (fsea_plan_set_window): the headline batch and BASELINE config
         # 5's 50 %-overlap STFT with a Hann taper, each beside its rectangular twin measured the same way in this run
-        h_steps = max(20, min(args.steps, 200))
+        # regions of at least 100 launches for this pair: a ratio of two 20-launch regions (1 ms each, from an idle chip) moved
+        # between 0.94 and 0.99 on one build from box to box; 100 launches per region settle it (same launch shape)
+        h_steps = max(100, min(args.steps, 200))
         r8 = run_gpu(args, "batch8192x4096", rank, world, dist, torch, h_steps, args.warmup, args.sets, repeats=R)
         h8 = run_gpu(args, "batch8192x4096", rank, world, dist, torch, h_steps, args.warmup, args.sets, repeats=R, window="hann")
-        st_steps = max(20, min(args.steps, 100))
+        st_steps = max(50, min(args.steps, 100))
         st = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2, repeats=R)
         sh = run_gpu(args, "stft16384x8191", rank, world, dist, torch, st_steps, min(args.warmup, 20), 2, repeats=R, window="hann")
         for tag, run_ in (("hann_n8192", h8), ("stft16384_hann", sh)):
