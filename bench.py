@@ -349,7 +349,7 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     # one GPU, resident captures: consecutive sweeps issued alternately on two streams, each with its own image -- one
     # launch's drain under the next one's ramp, what a double-buffered consumer of independent sweeps gets
     two_stream_ms = None
-    if world == 1 and not ingest and not args.no_fused_stitch:
+    if world == 1 and not ingest and not args.no_fused_stitch and not args.no_extra:   # (--no-extra: profiling runs want the one-stream launches alone)
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         images = [img, torch.empty_like(img)]
         torch.cuda.synchronize()
