@@ -269,6 +269,9 @@ enum : int { IN_U8 = 0, IN_F32 = 1, IN_U8_ROT = 2 };  // IN_U8_ROT: launch selec
 #endif
 // Per-workgroup time stamps (FftArgs::trace) are compiled into the tuning library only
 // (libfsea_hip_tune.so, -DFSEA_TRACE=1); the product kernels carry no trace code.
+#ifndef FSEA_STATIC_CONTIG
+#define FSEA_STATIC_CONTIG 0
+#endif
 #ifndef FSEA_TRACE
 #define FSEA_TRACE 0
 #endif
@@ -1159,6 +1162,15 @@ struct FftKernel {
         // starts streaming at once), the register-resident last-pass twiddles, then the
         // middle-pass tables for LDS.
         size_t u = b;  // static interleave (single-wave frames; short launches of the multi-wave sizes)
+#if FSEA_STATIC_CONTIG  // measurement only: each workgroup takes a contiguous run of units instead (profiles/r05_static_contiguous.txt)
+        [[maybe_unused]] const size_t contig_per = (n_units + gridDim.x - 1) / gridDim.x;
+        [[maybe_unused]] size_t contig_end = n_units;
+        if constexpr (!RUNS) {
+            u = (size_t)b * contig_per;
+            contig_end = u + contig_per < n_units ? u + contig_per : n_units;
+            if (u >= n_units) u = n_units;
+        }
+#endif
         unsigned tick_next = 0;
         // The ticket pools pay for themselves when a workgroup gets many units (they even out the unequal progress of
         // workgroups and XCDs); with a handful each, the plain interleave is faster -- no atomics, no ticket word to wait
@@ -1380,6 +1392,9 @@ struct FftKernel {
             // prefetch: the next unit is known to every lane now; its bytes stay in flight
             // during the rest of the transform
             size_t un = u + gridDim.x;
+#if FSEA_STATIC_CONTIG
+            if constexpr (!RUNS) un = u + 1 < contig_end ? u + 1 : n_units;
+#endif
             [[maybe_unused]] size_t fnext = 0;
             [[maybe_unused]] bool same_run = false;
             if constexpr (RUNS) {
