@@ -95,10 +95,38 @@ def synth_batch(seed, n_bytes):
     return out.view(np.uint8)
 
 
-def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repeats=1, window=None):
-    """K = `steps` timed steps of `workload` behind `warmup` untimed ones.  repeats > 1 (the informational `extra` runs):
-    the timed region is measured that many times back to back and the MEDIAN region is reported, so that a 20-step region
-    of a side workload is not one sample of a cold clock.  window: a taper name for fsea_plan_set_window, or None."""
+def settle_clock(torch, step, limit_s, block=64, agree=0.01, need=3, floor_s=0.25):
+    """Untimed steps in blocks of `block` launches until `need` consecutive block times agree within `agree` (max over
+    min of the last `need`) and at least min(floor_s, limit_s) seconds have passed (rounds 3-5 ran a fixed 0.25 s: never
+    less than that), for at most `limit_s` seconds.  Returns (seconds spent, blocks run); (0.0, 0) if limit_s <= 0."""
+    if limit_s <= 0:
+        return 0.0, 0
+    t_pre = time.perf_counter()
+    torch.cuda.synchronize()
+    times, k = [], 0
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(block):
+            step(k)
+            k += 1
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        times.append(now - t0)
+        last = times[-need:]
+        if (len(times) > need and max(last) <= (1.0 + agree) * min(last)       # (the first block is never one of the three)
+                and now - t_pre >= min(floor_s, limit_s)):
+            break
+        if now - t_pre >= limit_s:
+            break
+    return time.perf_counter() - t_pre, len(times)
+
+
+def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repeats=1, window=None, official_first=False):
+    """K = `steps` timed steps of `workload` behind `warmup` untimed ones.  repeats > 1: the timed region is measured that
+    many times back to back.  official_first (the headline): the FIRST region is the reported one -- the contract's W warm-ups
+    + exactly K timed steps -- and the later, identical regions are reported beside it (`regions`); otherwise (the
+    informational `extra` runs) the MEDIAN region is reported, so that a 20-step region of a side workload is not one
+    sample.  window: a taper name for fsea_plan_set_window, or None."""
     from frequensea_amd import fsea
 
     n, frames, hop = WORKLOADS[workload]
@@ -122,16 +150,13 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repea
         s = k % sets
         plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=stream)
 
-    # clock pre-warm (untimed, before the official warm-up, named in config.clock_prewarm_s): the shader clock
-    # needs tens of milliseconds of load to settle, far longer than W short steps.  It drives the chip to its
-    # power-capped clock, i.e. it lowers the number; --prewarm 0 switches it off.
-    t_pre = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t_pre < args.prewarm:
-        for _ in range(64):
-            step(k)
-            k += 1
-        torch.cuda.synchronize()
+    # clock settle loop (untimed, before the official warm-up; the seconds it took are named in config.clock_prewarm_s):
+    # 64-launch blocks until three consecutive block times agree within 1 %, bounded by --prewarm seconds.  The shader
+    # clock needs tens to hundreds of milliseconds of load to reach the package-power-capped state every later region
+    # of this process sees; a fixed 0.25 s (rounds 3-5) left the official K steps on the governor's transient on some
+    # boxes (BENCH_r05: the official 20-step region 7 % above its own process's medians).  Settling LOWERS the number
+    # (the settled clock is the capped one); --prewarm 0 switches it off.
+    prewarm_s, settle_blocks = settle_clock(torch, step, args.prewarm)
     for k in range(warmup):
         step(k)
     torch.cuda.synchronize()
@@ -153,11 +178,20 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repea
         t1 = time.perf_counter()
         walls.append(t1 - t0)
         kernels.append(ev0.elapsed_time(ev1) / steps)  # events on the launch stream
+        if rep == 0 and official_first and dist is not None:
+            dist.barrier()                             # the contract's closing bracket of THE timed region
+            torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    wall = float(np.median(walls))
-    kernel_ms = float(np.median(kernels))
+    if official_first:
+        # the headline: `value` is the FIRST K-step region (the bench contract: W warm-ups, then exactly K timed steps);
+        # the identical regions behind it only say how representative that one sample was
+        wall, kernel_ms = float(walls[0]), float(kernels[0])
+    else:
+        wall = float(np.median(walls))
+        kernel_ms = float(np.median(kernels))
+    regions = {"wall_ms_per_step": [1e3 * w / steps for w in walls], "events_ms_per_step": [float(x) for x in kernels]}
     if dist is not None:
         tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -173,7 +207,7 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repea
         # at 8192 points; scripts/two_stream_lengths.py, profiles/r04_two_stream_lengths.txt)
         t_pre = time.perf_counter()
         k = 0
-        while k < max(8, warmup) or time.perf_counter() - t_pre < args.prewarm:
+        while k < max(8, warmup) or time.perf_counter() - t_pre < min(args.prewarm, 0.25):
             for _ in range(64):
                 s = k % sets
                 plan.exec_device(ins[s].data_ptr(), frames, outs[s].data_ptr(), flip=True, stream=streams[k % 2].cuda_stream)
@@ -195,7 +229,8 @@ def run_gpu(args, workload, rank, world, dist, torch, steps, warmup, sets, repea
     grid = plan.grid(frames)
     plan.close()
     return dict(n=n, frames=frames, hop=hop, wall=wall, kernel_ms=kernel_ms, kernel=kname, grid=grid, two_stream=two_stream,
-                sample=sample, host_head=np.roll(host, 0)[: 2 * 4 * hop + 2 * n], steps=steps)
+                sample=sample, host_head=np.roll(host, 0)[: 2 * 4 * hop + 2 * n], steps=steps, regions=regions,
+                prewarm_s=prewarm_s, settle_blocks=settle_blocks)
 
 
 def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
@@ -303,7 +338,7 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
     torch.cuda.synchronize()
     # clock pre-warm, as for the headline workload (untimed; config.clock_prewarm_s)
     t_pre = time.perf_counter()
-    while world == 1 and time.perf_counter() - t_pre < args.prewarm:
+    while world == 1 and time.perf_counter() - t_pre < min(args.prewarm, 0.25):
         for _ in range(8):
             img = step()
         torch.cuda.synchronize()
@@ -441,7 +476,7 @@ def run_broad(args, rank, world, dist, torch, steps, warmup, repeats=1):
                                 "written in place by the FFT kernel (fsea_exec_u8_tiled_device), received ones copied in"),
                    "regime": ("ingest: captures start in pinned host memory, H2D inside the step (one PCIe link per GPU)"
                               if ingest else "resident: captures in HBM when the step starts (gather is xGMI-link-bound)"),
-                   "gather_chunks": n_chunks, "clock_prewarm_s": args.prewarm if world == 1 else 0.0,
+                   "gather_chunks": n_chunks, "clock_prewarm_s": min(args.prewarm, 0.25) if world == 1 else 0.0,
                    "parallelism": "centre frequencies sharded x%d, u8 tiles gathered by grouped send/recv" % world},
         "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
@@ -928,8 +963,11 @@ def main():
     ap.add_argument("--sets", type=int, default=6, help="independent buffer sets rotated per step")
     ap.add_argument("--no-fused-stitch", action="store_true",
                     help="broad: rank 0 stitches its own tiles with the composite kernel instead of writing them in place")
-    ap.add_argument("--prewarm", type=float, default=0.25,
-                    help="seconds of untimed steps in front of the --warmup steps (clock settling); 0 = none")
+    ap.add_argument("--prewarm", type=float, default=2.0,
+                    help="upper bound, seconds, of the untimed clock-settle loop in front of the --warmup steps (64-launch blocks "
+                         "until three consecutive ones agree within 1 %%; the seconds it took: config.clock_prewarm_s); 0 = none")
+    ap.add_argument("--regions", type=int, default=9,
+                    help="identical K-step regions measured BEHIND the official one (headline_regions_ms, official_over_median)")
     ap.add_argument("--window", default=None, choices=["hann", "hamming", "blackman"],
                     help="taper fused into pass 0 (fsea_plan_set_window); default: none = the reference's rectangular frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -984,7 +1022,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    res = run_gpu(args, args.workload, rank, world, dist, torch, args.steps, args.warmup, args.sets, window=args.window)
+    res = run_gpu(args, args.workload, rank, world, dist, torch, args.steps, args.warmup, args.sets, window=args.window,
+                  repeats=1 + max(0, args.regions), official_first=True)
     n, frames, hop = res["n"], res["frames"], res["hop"]
     # The timed region is the K steps between the opening and the closing barrier + device synchronise; `value` and
     # `ms_per_step` are the HOST WALL CLOCK of that region (MAX over ranks), as the bench contract defines them and as every
@@ -1018,7 +1057,10 @@ def main():
                                "MAG_F32 epilogue (nrf_fft_process semantics)%s" %
                                (args.workload, n, frames, ", %s taper fused into pass 0" % args.window if args.window else ""),
                    "fft_size": n, "frames_per_step_per_gpu": frames, "hop": hop, "window": args.window or "rectangular (the reference)",
-                   "buffer_sets": args.sets, "clock_prewarm_s": args.prewarm,
+                   "buffer_sets": args.sets, "clock_prewarm_s": res["prewarm_s"], "clock_prewarm_limit_s": args.prewarm,
+                   "clock_prewarm_blocks_of_64_launches": res["settle_blocks"],
+                   "clock_prewarm_rule": "untimed 64-launch blocks until three consecutive block times agree within 1 % "
+                                         "(at least 0.25 s, at most the limit), then the W warm-up steps",
                    "parallelism": "frames sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -1029,6 +1071,18 @@ def main():
                      "read_only_frac": (2 * hop * frames) / (res["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "grid_block_lds": list(res["grid"])},
     }
+    # How representative the ONE official sample is: the same K steps measured `--regions` more times straight behind it
+    # (rank 0's own clock; same buffers, same stream, nothing in between but the closing synchronise).  `value` /
+    # `ms_per_step` / `roofline` stay the official (first) region; min / median / max are over the regions BEHIND it.
+    rg = res["regions"]
+    if len(rg["wall_ms_per_step"]) > 1:
+        for key, src in (("headline_regions_ms", "wall_ms_per_step"), ("headline_regions_events_ms", "events_ms_per_step")):
+            later = rg[src][1:]
+            line[key] = {"official": rg[src][0], "min": float(np.min(later)), "median": float(np.median(later)),
+                         "max": float(np.max(later)), "regions_behind_official": len(later)}
+        line["official_over_median"] = line["headline_regions_ms"]["official"] / line["headline_regions_ms"]["median"]
+        line["official_over_median_events"] = (line["headline_regions_events_ms"]["official"]
+                                               / line["headline_regions_events_ms"]["median"])
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
@@ -1064,7 +1118,9 @@ def main():
             raise SystemExit("bench: GPU rows differ from the numpy guard (rel %.3e)" % rel)
 
     br = None
-    if world > 1 and args.workload == "batch8192x4096" and not args.window and not args.no_multi_gpu_leg:
+    if args.workload == "batch8192x4096" and not args.window and not args.no_extra:
+        start_guardian(line, rank)                                # from here on a hard failure still leaves the headline's line
+    if world > 1 and args.workload == "batch8192x4096" and not args.window and not args.no_multi_gpu_leg and not args.no_extra:
         # The driver's N > 1 command line: after the headline's steps, the workloads north_star actually scales over a node
         mg_flat, mg_lines = guarded_multi_gpu_leg(args, rank, world, dist, torch, line)
         line["extra"] = mg_flat
@@ -1184,10 +1240,54 @@ def main():
 _EMIT_LOCK = None
 _EMITTED = [False]
 _LEG_FAILED = [False]
+_GUARDIAN = [None]
+
+GUARDIAN_SCRIPT = r"""
+import json, sys
+provisional, final = None, None
+for raw in sys.stdin:
+    tag, _, body = raw.partition(" ")
+    if tag == "PROVISIONAL":
+        provisional = body
+    elif tag == "FINAL":
+        final = body
+        break
+if final is None and provisional is not None:
+    try:
+        d = json.loads(provisional)
+        d.setdefault("extra", {})["multi_gpu_error"] = ("the bench process ended without printing its line (killed or aborted "
+                                                        "inside the multi-GPU leg); this is the headline as measured before the leg")
+        final = json.dumps(d) + "\n"
+    except Exception:
+        final = provisional
+if final is not None:
+    sys.stdout.write(final if final.endswith("\n") else final + "\n")
+    sys.stdout.flush()
+"""
+
+
+def start_guardian(line, rank):
+    """the headline is measured before the multi-GPU leg, and a HARD failure inside the leg (an RCCL watchdog's
+    abort(), a GPU fault, SIGKILL / SIGTERM from the launcher after a peer died) cannot be caught by Python.  Rank 0 therefore
+    hands the line as it stands to a small child process (no GPU, no torch: it only reads its stdin) which becomes THE printer:
+    it prints the final line when main() delivers one, and the provisional one -- with extra.multi_gpu_error saying so -- if
+    its stdin closes without.  One line either way."""
+    import subprocess
+    if rank != 0 or _GUARDIAN[0] is not None:
+        return
+    try:
+        g = subprocess.Popen([sys.executable, "-c", GUARDIAN_SCRIPT], stdin=subprocess.PIPE, text=True)
+        g.stdin.write("PROVISIONAL " + json.dumps(line) + "\n")
+        g.stdin.flush()
+        _GUARDIAN[0] = g
+    except Exception as e:                                       # no guardian: main() prints by itself, as before
+        print("bench.py: no guardian process (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
+        _GUARDIAN[0] = None
 
 
 def emit_line(line, rank):
-    """Rank 0 prints THE one JSON line, once -- whether main() got to its end or the multi-GPU leg's watchdog fired first."""
+    """Rank 0 prints THE one JSON line, once -- whether main() got to its end or the multi-GPU leg's watchdog fired first
+    (through the guardian process when there is one: a single printer, so that no failure order can print two lines)."""
     global _EMIT_LOCK
     import threading
     if _EMIT_LOCK is None:
@@ -1197,7 +1297,22 @@ def emit_line(line, rank):
             return
         _EMITTED[0] = True
         if rank == 0:
-            print(json.dumps(line))
+            try:
+                text = json.dumps(line)
+            except Exception as e:                               # (a key of the wrong type from a half-finished stage)
+                text = json.dumps({k: v for k, v in line.items() if k != "extra"})
+                print("bench.py: line serialised without `extra` (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
+            g = _GUARDIAN[0]
+            if g is not None:
+                try:
+                    g.stdin.write("FINAL " + text + "\n")
+                    g.stdin.flush()
+                    g.stdin.close()
+                    g.wait(timeout=20)
+                    return
+                except Exception:
+                    pass                                         # the guardian is gone: print here
+            print(text)
             sys.stdout.flush()
 
 
@@ -1213,15 +1328,33 @@ def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
     limit = [float(args.multi_gpu_timeout)]
     partial = {}
 
+    done = threading.Event()
+
     def on_timeout():
-        msg = "the multi-GPU leg did not finish within %.0f s (stage: %s); line printed without it" % (limit[0], stage[0])
-        line.setdefault("extra", {}).update(dict(partial))   # the stages that did finish
-        line["extra"]["multi_gpu_error"] = msg
-        print("bench.py rank %d: %s" % (rank, msg), file=sys.stderr)
-        emit_line(line, rank)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        # runs on the timer's thread while the main thread may still be filling `partial`: every step is fenced, and the
+        # process leaves whatever happens in here
+        try:
+            if done.is_set():                                    # the leg finished while the timer was firing
+                return
+            msg = "the multi-GPU leg did not finish within %.0f s (stage: %s); line printed without it" % (limit[0], stage[0])
+            snap = None
+            for _ in range(5):                                   # a dict that changes size under the copy raises: try again
+                try:
+                    snap = json.loads(json.dumps(dict(partial), default=str))
+                    break
+                except Exception:
+                    time.sleep(0.01)
+            line.setdefault("extra", {})
+            if snap:
+                line["extra"].update(snap)                       # the stages that did finish
+            line["extra"]["multi_gpu_error"] = msg
+            print("bench.py rank %d: %s" % (rank, msg), file=sys.stderr)
+            emit_line(line, rank)
+        finally:
+            if not done.is_set():
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(0)
     dog = threading.Timer(limit[0], on_timeout)
     dog.daemon = True
     dog.start()
@@ -1236,10 +1369,12 @@ def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
         flat = dict(partial)                                     # the stages that did finish stay in the line
         flat["multi_gpu_error"] = "rank %d, stage %s: %s: %s" % (rank, stage[0], type(e).__name__, e)
         print("bench.py rank %d: multi-GPU leg failed in stage %s\n%s" % (rank, stage[0], traceback.format_exc()), file=sys.stderr)
+    done.set()
     dog.cancel()
     if dist is not None and not _LEG_FAILED[0]:
         # did every rank get through?  (a rank that failed is not here: a short watchdog then ends the wait)
         limit[0], stage[0] = 45.0, "closing census (a peer left the leg early: see its stderr)"
+        done.clear()
         dog = threading.Timer(limit[0], on_timeout)
         dog.daemon = True
         dog.start()
@@ -1251,6 +1386,7 @@ def guarded_multi_gpu_leg(args, rank, world, dist, torch, line):
         except BaseException as e:
             _LEG_FAILED[0] = True
             flat["multi_gpu_error"] = "closing census: %s: %s" % (type(e).__name__, e)
+    done.set()
     dog.cancel()
     return flat, lines
 

@@ -472,7 +472,11 @@ int launch_pow2(fsea_plan *p, int in_kind, const void *d_in, size_t n_frames, in
     a.ctr = p->d_ctr;
     if (e->counters == 2 || (e->counters == 1 && a.dynamic_units != 0)) {
         a.ctr = counter_slot(p, s, &slot, &record);
-        if (!a.ctr) return fail(FSEA_EHIP, "no ticket-counter slot for this launch (event creation failed, or %u captured streams)", FSEA_CTR_SLOTS);
+        if (!a.ctr) {
+            return fail(FSEA_EHIP, "no ticket-counter slot for this launch: all %u slots of the plan are reserved by streams with captured "
+                                   "launches (fsea_plan_release_stream once a stream's graphs are destroyed, or fsea_plan_reset), or an "
+                                   "event could not be created", FSEA_CTR_SLOTS);
+        }
     }
     if (kind >= fsea::K_U8_MAG_WIN) e->launch_win(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
     else e->launch(kind, a, grid_for(p, e, p->occ[kind], n_frames), s);
@@ -663,6 +667,31 @@ int fsea_plan_reset(fsea_plan *p) {
     {
         std::lock_guard<std::mutex> lock(p->slot_mu);
         for (auto &c : p->slots) c.used = c.pending = c.anonymous = c.captured = c.launching = false;
+    }
+    return FSEA_OK;
+}
+
+// Gives back the ticket-counter slot `stream` holds in this plan -- in particular one reserved by a captured launch -- once
+// the graphs captured on that stream are destroyed (an application that captures on short-lived streams would
+// otherwise run out of the 64 slots).  Waits for the slot's last un-captured launch; the slot's counters are left as every
+// finished launch leaves them (zero).  FSEA_OK also when the stream holds no slot.
+int fsea_plan_release_stream(fsea_plan *p, void *stream) {
+    if (!p) return fail(FSEA_EINVAL, "plan is NULL");
+    FSEA_ON_DEVICE(p->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (s != nullptr) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive) {
+            return fail(FSEA_EINVAL, "fsea_plan_release_stream: the stream is being captured");
+        }
+        (void)hipGetLastError();
+    }
+    std::lock_guard<std::mutex> lock(p->slot_mu);
+    for (auto &c : p->slots) {
+        if (!c.used || c.anonymous || c.stream != s) continue;
+        if (c.launching) return fail(FSEA_EINVAL, "fsea_plan_release_stream: another thread is launching on this stream");
+        if (c.pending && c.ev) FSEA_HIP(hipEventSynchronize(c.ev));
+        c.used = c.pending = c.captured = false;
     }
     return FSEA_OK;
 }

@@ -24,7 +24,7 @@ _MODE_DTYPE = {
 
 # Every symbol include/fsea.h declares; tests check the built library exports all of them.
 EXPORTS = [
-    "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_reset",
+    "fsea_device_count", "fsea_plan_create", "fsea_plan_destroy", "fsea_plan_reset", "fsea_plan_release_stream",
     "fsea_plan_grid", "fsea_plan_row_bytes", "fsea_plan_fft_size", "fsea_exec_u8_device", "fsea_exec_u8_tiled_device", "fsea_plan_set_unit_distribution",
     "fsea_exec_u8_host", "fsea_exec_f64_host", "fsea_exec_u8_shifted_device", "fsea_exec_u8_shifted_host", "fsea_mean_magnitude_u8_device",
     "fsea_composite_max_device", "fsea_stitch_tiles_device", "fsea_device_alloc", "fsea_device_free", "fsea_copy_to_device",
@@ -89,6 +89,7 @@ def hip_lib():
         L.fsea_device_count.argtypes = [ctypes.POINTER(ci)]
         L.fsea_plan_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci]
         L.fsea_plan_reset.argtypes = [vp]
+        L.fsea_plan_release_stream.argtypes = [vp, vp]
         L.fsea_history_create.argtypes = [vp, ci, ctypes.POINTER(vp)]
         L.fsea_history_destroy.argtypes = [vp]
         L.fsea_history_push_u8_host.argtypes = [vp, vp, ci]
@@ -239,6 +240,10 @@ class Plan:
 
     def reset(self):
         _check(self._L.fsea_plan_reset(self._p))
+
+    def release_stream(self, stream):
+        """fsea_plan_release_stream: give back the counter slot `stream` holds (after its captured graphs are destroyed)."""
+        _check(self._L.fsea_plan_release_stream(self._p, stream))
 
     def time_device(self, d_iq_ptr, n_frames, d_out_ptr, reps, flip=True, stream=0):
         """Tuning library only (fsea_time_exec_u8_device)."""

@@ -56,6 +56,7 @@ static void *deflate_slab(void *p) {
     const size_t stride = (size_t)sl->width + 1;
     sl->raw_len = stride * (size_t)sl->rows;
     sl->ok = 0;
+    if (sl->raw_len > 0xf0000000u) return NULL; /* zlib's avail_in / avail_out are 32 bits: write_gray_png sizes the slabs below that */
     uint8_t *raw = (uint8_t *)malloc(sl->raw_len);
     sl->out_cap = compressBound((uLong)sl->raw_len) + 64;
     sl->out = (uint8_t *)malloc(sl->out_cap);
@@ -89,10 +90,59 @@ static void *deflate_slab(void *p) {
 #include <pthread.h>
 #include <unistd.h>
 
+/* IDAT chunks written as a stream: `left` bytes of zlib data are still to come in all; a chunk is opened with
+ * min(left, PNG_IDAT_MAX) bytes, filled by idat_put from however many pieces, and closed with its CRC when full. */
+#define PNG_IDAT_MAX ((size_t)1 << 30)
+typedef struct {
+    FILE *fp;
+    size_t chunk_max; /* bytes per IDAT chunk at most */
+    size_t left;     /* zlib bytes not yet handed to idat_put */
+    size_t in_chunk; /* bytes the open chunk still takes; 0 = no chunk open */
+    uLong crc;
+} idat_stream;
+
+static int idat_put(idat_stream *st, const uint8_t *data, size_t len) {
+    while (len > 0) {
+        if (st->in_chunk == 0) {
+            if (st->left == 0) return -1;
+            const size_t take = st->left < st->chunk_max ? st->left : st->chunk_max;
+            uint8_t head[8];
+            put_u32(head, (uint32_t)take);
+            memcpy(head + 4, "IDAT", 4);
+            if (fwrite(head, 1, 8, st->fp) != 8) return -1;
+            st->crc = crc32(0L, head + 4, 4);
+            st->in_chunk = take;
+        }
+        size_t n = len < st->in_chunk ? len : st->in_chunk;
+        if (n > st->left) return -1;
+        /* crc32 takes a uInt length */
+        for (size_t off = 0; off < n;) {
+            const size_t piece = n - off < ((size_t)1 << 30) ? n - off : ((size_t)1 << 30);
+            st->crc = crc32(st->crc, data + off, (uInt)piece);
+            off += piece;
+        }
+        if (fwrite(data, 1, n, st->fp) != n) return -1;
+        data += n;
+        len -= n;
+        st->in_chunk -= n;
+        st->left -= n;
+        if (st->in_chunk == 0) {
+            uint8_t tail[4];
+            put_u32(tail, (uint32_t)st->crc);
+            if (fwrite(tail, 1, 4, st->fp) != 4) return -1;
+        }
+    }
+    return 0;
+}
+
 #define PNG_MAX_SLABS 8
 #define PNG_SLAB_MIN_BYTES ((size_t)1 << 18) /* bytes per slab at least: smaller images are one slab, compressed on the calling thread */
 
 int write_gray_png(const char *fname, int width, int height, const uint8_t *buffer) {
+    return write_gray_png_chunked(fname, width, height, buffer, PNG_IDAT_MAX);
+}
+
+int write_gray_png_chunked(const char *fname, int width, int height, const uint8_t *buffer, size_t idat_max) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (width <= 0 || height <= 0 || buffer == NULL) {
         printf("ERROR: invalid image %d x %d.\n", width, height);
@@ -129,24 +179,20 @@ int write_gray_png(const char *fname, int width, int height, const uint8_t *buff
         else deflate_slab(&slabs[k]); /* no thread to be had: compress it here */
     }
     int rc = -1;
-    size_t zlen = 2 + 4;
     int all_ok = 1;
-    for (int k = 0; k < n_slabs; k++) {
-        all_ok = all_ok && slabs[k].ok;
-        zlen += slabs[k].out_len;
-    }
-    uint8_t *z = all_ok && zlen <= 0x7fffffffu ? (uint8_t *)malloc(zlen) : NULL;
-    if (z) {
-        size_t pos = 2;
+    for (int k = 0; k < n_slabs; k++) all_ok = all_ok && slabs[k].ok;
+    if (all_ok) {
+        /* the zlib stream = 2-byte header, the slabs' deflate output, Adler-32 of the raw bytes; written as IDAT chunks of at
+         * most PNG_IDAT_MAX bytes each (a chunk length is 31 bits; libpng, which the reference links, splits likewise).  The
+         * reference's own stitched image is 154112 x 11811 (c/fft-stitch.c:16-27): 1.8 GB of scanlines in one IDAT would sit
+         * just under that limit, the same sweep at full tile height above it. */
+        uint8_t zhead[2] = {0x78, 0x9c}; /* deflate, 32 KiB window; default compression, no dictionary (0x789c % 31 == 0) */
+        uint8_t ztail[4];
         uLong adler = adler32(0L, Z_NULL, 0);
-        z[0] = 0x78; /* deflate, 32 KiB window */
-        z[1] = 0x9c; /* default compression, no dictionary; (0x789c % 31 == 0) */
         for (int k = 0; k < n_slabs; k++) {
-            memcpy(z + pos, slabs[k].out, slabs[k].out_len);
-            pos += slabs[k].out_len;
             adler = (k == 0) ? slabs[k].adler : adler32_combine(adler, slabs[k].adler, (z_off_t)slabs[k].raw_len);
         }
-        put_u32(z + pos, (uint32_t)adler);
+        put_u32(ztail, (uint32_t)adler);
         uint8_t ihdr[13];
         put_u32(ihdr, (uint32_t)width);
         put_u32(ihdr + 4, (uint32_t)height);
@@ -155,13 +201,18 @@ int write_gray_png(const char *fname, int width, int height, const uint8_t *buff
         ihdr[10] = 0; /* deflate */
         ihdr[11] = 0; /* adaptive filtering */
         ihdr[12] = 0; /* no interlace */
-        if (fwrite(sig, 1, 8, fp) == 8 && write_chunk(fp, "IHDR", ihdr, 13) == 0 &&
-            write_chunk(fp, "IDAT", z, (uint32_t)zlen) == 0 && write_chunk(fp, "IEND", NULL, 0) == 0) {
-            rc = 0;
-        }
+        idat_stream st;
+        memset(&st, 0, sizeof(st));
+        st.fp = fp;
+        st.chunk_max = idat_max < 1 ? 1 : idat_max > PNG_IDAT_MAX ? PNG_IDAT_MAX : idat_max;
+        st.left = 2 + 4;
+        for (int k = 0; k < n_slabs; k++) st.left += slabs[k].out_len;
+        int ok = fwrite(sig, 1, 8, fp) == 8 && write_chunk(fp, "IHDR", ihdr, 13) == 0 && idat_put(&st, zhead, 2) == 0;
+        for (int k = 0; ok && k < n_slabs; k++) ok = idat_put(&st, slabs[k].out, slabs[k].out_len) == 0;
+        ok = ok && idat_put(&st, ztail, 4) == 0 && st.left == 0 && st.in_chunk == 0;
+        if (ok && write_chunk(fp, "IEND", NULL, 0) == 0) rc = 0;
     }
     for (int k = 0; k < n_slabs; k++) free(slabs[k].out);
-    free(z);
     if (fclose(fp) != 0) rc = -1;
     if (rc == 0) {
         printf("Written %s.\n", fname);

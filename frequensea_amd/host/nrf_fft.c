@@ -26,7 +26,11 @@
  * lua/fft-shifted.lua:52-55 is tapered too) and in both history modes:
  * fsea_plan_set_window on the block's plan, fused into the kernel's pass 0.
  * Unset (or "rect" / "none") is the reference: it has no taper, the API keeps
- * its signatures, and the scenes need no change to get one.
+ * its signatures, and the scenes need no change to get one.  That variable is
+ * only the DEFAULT of new blocks: nrf_fft_set_window(fft, name) and
+ * nrf_fft_set_window_weights(fft, w) -- two ADDITIONS beside the reference's five
+ * prototypes (src/nrf.h:138-142), nothing existing changes -- choose the taper
+ * per nrf_fft object, at any time between process calls, in both history modes.
  */
 #include <math.h>
 #include <stdio.h>
@@ -49,6 +53,63 @@ static void fsea_fatal(const char *what, int rc) {
     exit(EXIT_FAILURE);
 }
 
+/* taper names of nrf_fft_set_window / NRF_FFT_WINDOW -> fsea_window_fill kinds; -1 = rectangular (no taper), -2 = unknown */
+static int fsea_window_kind(const char *name) {
+    static const struct { const char *name; int kind; } tapers[] = {
+        {"hann", FSEA_WINDOW_HANN},           {"hamming", FSEA_WINDOW_HAMMING}, {"blackman", FSEA_WINDOW_BLACKMAN},
+        {"blackmanharris", FSEA_WINDOW_BLACKMANHARRIS}, {"flattop", FSEA_WINDOW_FLATTOP}};
+    if (name == NULL || name[0] == '\0' || strcmp(name, "rect") == 0 || strcmp(name, "none") == 0) return -1;
+    for (size_t i = 0; i < sizeof(tapers) / sizeof(tapers[0]); i++) {
+        if (strcmp(name, tapers[i].name) == 0) return tapers[i].kind;
+    }
+    return -2;
+}
+
+static void set_window_by_name(fsea_plan *plan, int fft_size, const char *name, const char *who) {
+    const int kind = fsea_window_kind(name);
+    int rc;
+    if (kind == -1) {
+        rc = fsea_plan_set_window(plan, NULL);
+        if (rc != FSEA_OK) fsea_fatal("fsea_plan_set_window", rc);
+        return;
+    }
+    float *w = (float *)malloc(sizeof(float) * (size_t)fft_size);
+    if (w == NULL) {
+        fprintf(stderr, "NRF FFT fatal error: out of memory\n");
+        exit(EXIT_FAILURE);
+    }
+    rc = fsea_window_fill(kind, fft_size, w);
+    if (rc != FSEA_OK) fsea_fatal("fsea_window_fill", rc);
+    rc = fsea_plan_set_window(plan, w); /* fails for a size without a kernel of its own: said loudly, not ignored */
+    if (rc != FSEA_OK) {
+        char what[96];
+        snprintf(what, sizeof(what), "fsea_plan_set_window (%s)", who);
+        fsea_fatal(what, rc);
+    }
+    free(w);
+}
+
+void nrf_fft_set_window(nrf_fft *fft, const char *name) {
+    if (fsea_window_kind(name) == -2) {
+        /* a programming error in the scene, handled as src/main.cpp handles a wrong argument type: say it and stop */
+        fprintf(stderr, "NRF FFT fatal error: nrf_fft_set_window: \"%s\" is not one of hann, hamming, blackman, blackmanharris, "
+                        "flattop, rect\n", name);
+        exit(EXIT_FAILURE);
+    }
+    /* under the block's mutex: a device thread may be inside nrf_fft_process (SURVEY 8(b) threading); rows already in the
+     * history stay as they were computed, the next process call uses the new taper */
+    pthread_mutex_lock(&fft->mutex);
+    set_window_by_name((fsea_plan *)fft->backend, fft->fft_size, name, "nrf_fft_set_window");
+    pthread_mutex_unlock(&fft->mutex);
+}
+
+void nrf_fft_set_window_weights(nrf_fft *fft, const float *weights) {
+    pthread_mutex_lock(&fft->mutex);
+    const int rc = fsea_plan_set_window((fsea_plan *)fft->backend, weights); /* NULL: back to the reference's rectangular frames */
+    if (rc != FSEA_OK) fsea_fatal("fsea_plan_set_window (nrf_fft_set_window_weights)", rc);
+    pthread_mutex_unlock(&fft->mutex);
+}
+
 nrf_fft *nrf_fft_new(int fft_size, int fft_history_size) {
     nrf_fft *fft = (nrf_fft *)calloc(1, sizeof(nrf_fft));
     if (fft == NULL) {
@@ -64,30 +125,16 @@ nrf_fft *nrf_fft_new(int fft_size, int fft_history_size) {
     int rc = fsea_plan_create(&plan, fft_size, fft_size, FSEA_MODE_MAG_F32, dev_env ? atoi(dev_env) : 0);
     if (rc != FSEA_OK) fsea_fatal("fsea_plan_create", rc);
     fft->backend = plan;
+    /* the process-wide default for scenes that do not ask (an unmodified fft-sea.lua gets a taper this way); a scene or a
+     * C caller that wants its own calls nrf_fft_set_window afterwards */
     const char *win_env = getenv("NRF_FFT_WINDOW");
-    if (win_env != NULL && win_env[0] != '\0' && strcmp(win_env, "rect") != 0 && strcmp(win_env, "none") != 0) {
-        static const struct { const char *name; int kind; } tapers[] = {
-            {"hann", FSEA_WINDOW_HANN},           {"hamming", FSEA_WINDOW_HAMMING}, {"blackman", FSEA_WINDOW_BLACKMAN},
-            {"blackmanharris", FSEA_WINDOW_BLACKMANHARRIS}, {"flattop", FSEA_WINDOW_FLATTOP}};
-        int kind = -1;
-        for (size_t i = 0; i < sizeof(tapers) / sizeof(tapers[0]); i++) {
-            if (strcmp(win_env, tapers[i].name) == 0) kind = tapers[i].kind;
-        }
-        if (kind < 0) {
+    if (win_env != NULL && win_env[0] != '\0') {
+        if (fsea_window_kind(win_env) == -2) {
             fprintf(stderr, "NRF FFT fatal error: NRF_FFT_WINDOW=%s is not one of hann, hamming, blackman, blackmanharris, "
                             "flattop, rect\n", win_env);
             exit(EXIT_FAILURE);
         }
-        float *w = (float *)malloc(sizeof(float) * (size_t)fft_size);
-        if (w == NULL) {
-            fprintf(stderr, "NRF FFT fatal error: out of memory\n");
-            exit(EXIT_FAILURE);
-        }
-        rc = fsea_window_fill(kind, fft_size, w);
-        if (rc != FSEA_OK) fsea_fatal("fsea_window_fill", rc);
-        rc = fsea_plan_set_window(plan, w); /* fails for a size without a kernel of its own: said loudly, not ignored */
-        if (rc != FSEA_OK) fsea_fatal("fsea_plan_set_window (NRF_FFT_WINDOW)", rc);
-        free(w);
+        set_window_by_name(plan, fft_size, win_env, "NRF_FFT_WINDOW");
     }
     const char *hist_env = getenv("NRF_FFT_HISTORY");
     if (hist_env != NULL && strcmp(hist_env, "device") == 0) {

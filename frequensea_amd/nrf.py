@@ -18,6 +18,8 @@ NUT_EXPORTS = [
     "nut_buffer_get_u8", "nut_buffer_get_f64", "nut_buffer_set_u8", "nut_buffer_set_f64",
     "nut_buffer_convert", "nut_buffer_save", "nut_buffer_free",
 ]
+# additions beside the reference's prototypes (include/nrf.h says so at each): the reference's nrf.h has no such function
+NRF_ADDITIONS = ["nrf_fft_set_window", "nrf_fft_set_window_weights"]
 NRF_EXPORTS = [
     "nrf_block_init", "nrf_block_connect", "nrf_block_process", "nrf_device_new",
     "nrf_device_new_with_config", "nrf_device_set_frequency", "nrf_device_set_decode_handler",
@@ -114,6 +116,10 @@ def nrf_lib():
         L.nrf_fft_get_buffer.argtypes = [vp]
         L.nrf_fft_free.restype = None
         L.nrf_fft_free.argtypes = [vp]
+        L.nrf_fft_set_window.restype = None
+        L.nrf_fft_set_window.argtypes = [vp, ctypes.c_char_p]
+        L.nrf_fft_set_window_weights.restype = None
+        L.nrf_fft_set_window_weights.argtypes = [vp, ctypes.c_void_p]
         L.nrf_freq_shifter_new.restype = vp
         L.nrf_freq_shifter_new.argtypes = [ctypes.c_int, ctypes.c_int]
         L.nrf_freq_shifter_process_samples.restype = None

@@ -176,8 +176,9 @@ int fsea_plan_set_unit_distribution(fsea_plan *plan, int policy);
  * launch keeps the ticket-counter slot of the stream it was captured on: replay one instance of such a graph at a
  * time, on the stream it was captured on or in order with that stream's other launches of the plan.  The slot stays
  * reserved for that stream until fsea_plan_reset (the graph's kernel node holds its address; the stream's own un-captured
- * launches go on using it): at most 64 distinct streams may hold captured launches of one plan (fsea_plan_reset releases
- * them all and invalidates the graphs).  Plans of the sizes without a
+ * launches go on using it): at most 64 distinct streams may hold captured launches of one plan at a time
+ * (fsea_plan_release_stream gives one stream's slot back once its graphs are destroyed; fsea_plan_reset releases them all
+ * and invalidates the graphs).  Plans of the sizes without a
  * kernel of their own (Bluestein / four-step) refuse a capturing stream with FSEA_EINVAL. */
 int fsea_exec_u8_device(fsea_plan *plan, const void *d_iq, size_t n_frames, int flip,
                         void *d_out, void *stream);
@@ -291,6 +292,12 @@ int fsea_copy_to_host_async(int device, void *dst, const void *d_src, size_t byt
 /* Recovery after an aborted launch (device fault, killed context): waits for the device and
  * re-zeroes the plan's internal frame-distribution counters.  Not needed in normal operation. */
 int fsea_plan_reset(fsea_plan *plan);
+
+/* Gives back the frame-distribution counter slot `stream` holds in this plan, in particular one reserved by a captured
+ * launch: call it once the hipGraphs captured on that stream are destroyed (before destroying the stream), so that an
+ * application capturing on short-lived streams does not run out of the 64 slots.  Waits for the stream's last un-captured
+ * launch of the plan.  FSEA_OK also when the stream holds no slot; FSEA_EINVAL while the stream is capturing. */
+int fsea_plan_release_stream(fsea_plan *plan, void *stream);
 
 /* Name of the kernel the plan launches for raw int8 input (flip != 0), for matching rocprof rows:
  * MAG_F32, DB5_U8_DCFIX and DB10_U8 plans have compile-time kernels (`*_u8_mag`, `*_u8_db5`,

@@ -146,6 +146,18 @@ void nrf_fft_process(nrf_fft *fft, nut_buffer *buffer);
  * nut_buffer_free (src/nrf.c:633-635). */
 nut_buffer *nrf_fft_get_buffer(nrf_fft *fft);
 void nrf_fft_free(nrf_fft *fft);
+/* ADDITIONS (not in the reference; the five prototypes above are src/nrf.h:138-142 unchanged).  BASELINE's north_star
+ * names a "windowed 1D FFT"; the reference's only pre-FFT weight is powf(-1, ii) (src/nrf.c:611-612), i.e. rectangular.
+ * A taper w[n] rides beside that sign in the kernel's fused unpack prologue: x[n] = (-1)^n w[n] u8[n]/256 (fsea.h:
+ * fsea_plan_set_window).  Per nrf_fft object; callable at any time, also between nrf_fft_process calls and from another
+ * thread (taken under the block's mutex): rows already in the history keep the taper they were computed with.
+ *   name: "hann", "hamming", "blackman", "blackmanharris", "flattop" (periodic, scipy.signal.get_window's values), or
+ *         "rect" / "none" / "" / NULL = the reference's rectangular frames.  Anything else: message on stderr + exit, the
+ *         reference's convention for a wrong argument (src/main.cpp:46-60).
+ *   weights: fft_size floats, copied; NULL = rectangular.
+ * The environment variable NRF_FFT_WINDOW=<name> is the default every nrf_fft_new starts from (unmodified scenes). */
+void nrf_fft_set_window(nrf_fft *fft, const char *name);
+void nrf_fft_set_window_weights(nrf_fft *fft, const float *weights);
 
 /* ---- frequency shifter (src/nrf.h:192-207, src/nrf.c:817-870) ------------ */
 

@@ -1569,6 +1569,55 @@ def test_launches_can_be_captured_into_a_hip_graph():
         plan.close()
 
 
+def test_captured_streams_give_their_counter_slot_back():
+    """A captured launch reserves its stream's ticket-counter slot (the graph's kernel node holds the address).  An
+    application that captures on short-lived streams hands each slot back with fsea_plan_release_stream once the graph is
+    gone (ADVICE r05): 80 capture / replay / release rounds on one plan (64 slots) all work and give the direct rows;
+    without the release the plan runs out and says which call frees them."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, nf = 8192, 96
+    iq = torch.from_numpy(synth_iq(83, 2 * nf * n).copy()).to(dev)
+    out = torch.zeros(nf * n, dtype=torch.float32, device=dev)
+    plan = fsea.Plan(n)
+    plan.set_unit_distribution(fsea.UNITS_TICKETS)
+    plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = out.clone()
+    for rnd in range(80):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), rnd
+        del graph
+        plan.release_stream(side.cuda_stream)
+    plan.release_stream(0)                                  # a stream without a slot: nothing to do, FSEA_OK
+    plan.close()
+    plan = fsea.Plan(n)
+    plan.set_unit_distribution(fsea.UNITS_TICKETS)
+    keep = []
+    with pytest.raises(fsea.FseaError, match="fsea_plan_release_stream"):
+        for rnd in range(70):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            keep.append((side, graph))
+    torch.cuda.synchronize()
+    del keep
+    plan.reset()
+    plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    plan.close()
+
+
 def test_windowed_launches_capture_too_and_the_anysize_paths_refuse_a_capturing_stream():
     """A windowed plan's launch is one kernel as well (replayed rows equal the direct ones); a plan of a size without a
     kernel of its own (Bluestein: several launches through plan-owned work buffers, ordered by events) refuses a

@@ -359,6 +359,88 @@ def test_nrf_fft_with_a_taper_from_the_environment(golden, monkeypatch, history,
     L.nrf_fft_free(fft)
 
 
+@pytest.mark.parametrize("history", ["host", "device"])
+def test_two_nrf_fft_objects_choose_their_own_taper(golden, monkeypatch, history):
+    """nrf_fft_set_window / nrf_fft_set_window_weights (include/nrf.h: additions beside the reference's five prototypes,
+    VERDICT r05 item 4): two nrf_fft objects of one process carry different tapers at the same time, a third stays
+    rectangular (the golden rows), the taper changes between process calls -- rows already in the history keep theirs --
+    and the caller's own weights arrive bit for bit; NRF_FFT_WINDOW is only what a new block starts from."""
+    from frequensea_amd import nrf
+    monkeypatch.setenv("NRF_FFT_HISTORY", history)
+    monkeypatch.delenv("NRF_FFT_WINDOW", raising=False)
+    L = nrf.nrf_lib()
+    raw = golden["rf_202p500_2__flipped"]                       # device buffers are offset binary
+    n, h = 1024, 8
+    buf = L.nut_buffer_new_u8(raw.size // 2, 2, raw.ctypes.data)
+    ffts = {name: L.nrf_fft_new(n, h) for name in ("hann", "blackmanharris", "rect")}
+    L.nrf_fft_set_window(ffts["hann"], b"hann")
+    L.nrf_fft_set_window(ffts["blackmanharris"], b"blackmanharris")
+
+    def newest(fft):
+        out = L.nrf_fft_get_buffer(fft)
+        hist = nrf.buffer_to_numpy(L, out).reshape(h, n)
+        L.nut_buffer_free(out)
+        return hist
+
+    def want(name):
+        if name == "rect":
+            return O.rows(raw, 1, n, flip=False)[0]
+        return O.rows_windowed(raw, 1, n, O.window(name, n).astype(np.float32).astype(np.float64), flip=False)[0]
+
+    for rnd in range(2):                                        # interleaved: nothing of one object leaks into another
+        for name, fft in ffts.items():
+            L.nrf_fft_process(fft, buf)
+        for name, fft in ffts.items():
+            parity.check_float(newest(fft)[0], want(name))
+    parity.check_float(newest(ffts["rect"])[0], golden["rf_202p500_2__mag_1024"])
+    assert np.linalg.norm(newest(ffts["hann"])[0] - newest(ffts["blackmanharris"])[0]) > 1.0
+    # a change between process calls: the next row has the new taper, the rows below keep the one they were computed with
+    fft = ffts["hann"]
+    L.nrf_fft_set_window(fft, b"flattop")
+    L.nrf_fft_process(fft, buf)
+    L.nrf_fft_set_window(fft, None)                             # NULL / "" / "rect" / "none": the reference's frames
+    L.nrf_fft_process(fft, buf)
+    ramp = (0.25 + np.arange(n) / n).astype(np.float32)         # not a cosine sum: the offset-binary form of the kernel
+    L.nrf_fft_set_window_weights(fft, ramp.ctypes.data)
+    L.nrf_fft_process(fft, buf)
+    f64 = L.nut_buffer_convert(buf, nrf.NUT_BUFFER_F64)         # the F64 branch (src/nrf.c:607-612) with the caller's weights
+    L.nrf_fft_process(fft, f64)
+    hist = newest(fft)
+    x = np.ctypeslib.as_array(f64.contents.data.f64, shape=(raw.size,)).copy()
+    parity.check_float(hist[0], O.rows_f64(x.astype(np.float32).astype(np.float64), 1, n, window=ramp.astype(np.float64))[0])
+    parity.check_float(hist[1], O.rows_windowed(raw, 1, n, ramp.astype(np.float64), flip=False)[0])
+    parity.check_float(hist[2], want("rect"))
+    parity.check_float(hist[3], want("flattop"))
+    parity.check_float(hist[4], want("hann"))
+    parity.check_float(hist[5], want("hann"))
+    assert not hist[6:].any()
+    L.nrf_fft_set_window_weights(fft, None)
+    L.nrf_fft_process(fft, buf)
+    assert np.array_equal(newest(fft)[0], newest(ffts["rect"])[0])   # back to the un-windowed kernel's bits
+    # the environment is the default of NEW blocks only; an explicit call overrides it
+    monkeypatch.setenv("NRF_FFT_WINDOW", "hamming")
+    fresh = L.nrf_fft_new(n, h)
+    L.nrf_fft_process(fresh, buf)
+    parity.check_float(newest(fresh)[0], want("hamming"))
+    L.nrf_fft_set_window(fresh, b"rect")
+    L.nrf_fft_process(fresh, buf)
+    assert np.array_equal(newest(fresh)[0], newest(ffts["rect"])[0])
+    L.nrf_fft_free(fresh)
+    for b in (f64, buf):
+        L.nut_buffer_free(b)
+    for fft in ffts.values():
+        L.nrf_fft_free(fft)
+
+
+def test_nrf_fft_set_window_refuses_an_unknown_name_loudly():
+    import subprocess
+    import sys
+    code = ("from frequensea_amd import nrf; L = nrf.nrf_lib(); f = L.nrf_fft_new(1024, 4); "
+            "L.nrf_fft_set_window(f, b'hamster'); print('not reached')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 1 and 'nrf_fft_set_window: "hamster"' in r.stderr and "not reached" not in r.stdout
+
+
 def test_nrf_fft_refuses_an_unknown_taper_loudly():
     """The reference's error convention (src/nrf.c:54-78): print and exit(EXIT_FAILURE)."""
     import subprocess

@@ -82,7 +82,7 @@ def test_comm_library_exports_every_declared_symbol():
 
 def test_nrf_exports_every_declared_symbol():
     L = ctypes.CDLL(nrf.lib_path())
-    for header, listed in (("nut.h", nrf.NUT_EXPORTS), ("nrf.h", nrf.NRF_EXPORTS)):
+    for header, listed in (("nut.h", nrf.NUT_EXPORTS), ("nrf.h", nrf.NRF_EXPORTS + nrf.NRF_ADDITIONS)):
         names = {n for n in declared_functions(header) if not n.endswith("_fn")}
         assert names == set(listed), names ^ set(listed)
         for name in names:
@@ -92,8 +92,8 @@ def test_nrf_exports_every_declared_symbol():
 def test_easypng_exports():
     L = ctypes.CDLL(nrf.lib_path())
     text = open(os.path.join(ROOT, "include", "easypng.h")).read()
-    names = set(re.findall(r"\b((?:write|read)_gray_png)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
-    assert names == {"write_gray_png", "read_gray_png"}
+    names = set(re.findall(r"\b((?:write|read)_gray_png\w*)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+    assert names == {"write_gray_png", "write_gray_png_chunked", "read_gray_png"}
     for name in names:
         assert hasattr(L, name)
 
@@ -266,6 +266,45 @@ def test_png_writer_deflates_large_images_in_slabs(tmp_path):
             pos += 12 + ln
         raw = zlib.decompress(idat)                      # checks the combined Adler-32 too
         assert len(raw) == shape[0] * (shape[1] + 1)
+
+
+def test_png_writer_splits_the_compressed_data_into_idat_chunks(tmp_path):
+    """A PNG chunk length is 31 bits, and the reference's own stitched image (154112 x 11811, c/fft-stitch.c:16-27) is
+    1.8 GB of scanlines: the writer cuts the zlib stream into IDAT chunks (2^30 bytes by default, any size through
+    write_gray_png_chunked), as libpng does for the reference.  Tiny chunk limits here, cutting inside the zlib header, the
+    slabs and the Adler-32; decoded by PIL, by zlib chunk by chunk, and by this library's reader."""
+    import struct
+    import zlib
+    from PIL import Image
+    L = ctypes.CDLL(nrf.lib_path())
+    L.write_gray_png_chunked.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    L.read_gray_png.restype = ctypes.POINTER(ctypes.c_uint8)
+    L.read_gray_png.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    rng = np.random.default_rng(6)
+    for shape, limit in (((37, 256), 1), ((37, 256), 7), ((2100, 1024), 8192), ((2100, 1024), 1000003), ((5, 9), 1 << 40)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        path = str(tmp_path / "chunks.png")
+        assert L.write_gray_png_chunked(path.encode(), shape[1], shape[0], img.ctypes.data, limit) == 0
+        data = open(path, "rb").read()
+        pos, lens, idat = 8, [], b""
+        while pos < len(data):
+            ln, typ = struct.unpack(">I4s", data[pos:pos + 8])
+            assert zlib.crc32(data[pos + 4: pos + 8 + ln]) == struct.unpack(">I", data[pos + 8 + ln: pos + 12 + ln])[0]
+            if typ == b"IDAT":
+                lens.append(ln)
+                idat += data[pos + 8: pos + 8 + ln]
+            pos += 12 + ln
+        assert pos == len(data) and max(lens) <= limit and all(x == min(limit, 1 << 30) for x in lens[:-1]) and lens[-1] > 0
+        if limit < len(idat):
+            assert len(lens) == -(-len(idat) // limit) > 1
+        else:
+            assert len(lens) == 1
+        assert len(zlib.decompress(idat)) == shape[0] * (shape[1] + 1)
+        with Image.open(path) as im:
+            assert im.mode == "L" and np.array_equal(np.array(im), img)
+        w, h = ctypes.c_int(), ctypes.c_int()
+        p = L.read_gray_png(path.encode(), ctypes.byref(w), ctypes.byref(h))
+        assert (h.value, w.value) == shape and np.array_equal(np.ctypeslib.as_array(p, shape=shape), img)
 
 
 def test_png_writer_and_reader_against_pil(tmp_path):

@@ -31,6 +31,9 @@ def test_every_function_has_the_reference_prototype(tmp_path):
     nrf_protos = _prototypes("nrf.h", set(nrf.NRF_EXPORTS))
     assert set(nut) == set(nrf.NUT_EXPORTS), set(nrf.NUT_EXPORTS) ^ set(nut)
     assert set(nrf_protos) == set(nrf.NRF_EXPORTS), set(nrf.NRF_EXPORTS) ^ set(nrf_protos)
+    # the additions (nrf_fft_set_window*) are additions: the reference's header declares no function of those names, and
+    # every function it does declare on this path is still here with its own prototype text (the redeclaration below)
+    assert not _prototypes("nrf.h", set(nrf.NRF_ADDITIONS))
     src = tmp_path / "redeclare.c"
     src.write_text('#include "nut.h"\n#include "nrf.h"\n' +
                    "".join(p + ";\n" for p in list(nut.values()) + list(nrf_protos.values())))
@@ -97,6 +100,8 @@ int main(int argc, char **argv) {
         nrf_fft_process(fft, in);
         nut_buffer *out = nrf_fft_get_buffer(fft);
         nrf_fft_shift(fft, 8.0);
+        nrf_fft_set_window(fft, "hann");     /* the additions (include/nrf.h) link the same way */
+        nrf_fft_set_window_weights(fft, NULL);
         nut_buffer_free(out);
         nut_buffer_free(in);
         nrf_fft_free(fft);
@@ -137,4 +142,5 @@ def test_fft_only_library_links_next_to_the_reference_nut(tmp_path):
     syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(pkg, "libfsea_nrf_fft.so")],
                           capture_output=True, text=True, check=True).stdout.split()
     defined = sorted(s for s in syms if s.startswith("nrf_") or s.startswith("nut_"))
-    assert defined == ["nrf_fft_free", "nrf_fft_get_buffer", "nrf_fft_new", "nrf_fft_process", "nrf_fft_shift"]
+    assert defined == ["nrf_fft_free", "nrf_fft_get_buffer", "nrf_fft_new", "nrf_fft_process", "nrf_fft_set_window",
+                       "nrf_fft_set_window_weights", "nrf_fft_shift"]       # the reference's five + the two taper additions
