@@ -80,9 +80,12 @@ static void writer_register(int member, png_writer *w) {
 static void writer_retire(int member) { writer_register(member, NULL); }
 static void fatal_exit(void) {
     pthread_mutex_lock(&g_fatal_mu); /* one thread ends the process; a second fatal error waits here until it has */
+    /* ONE absolute deadline for all members' writers and both of their slots: the fatal path ends within about 30 s in
+     * all, not 60 s per member one after the other */
+    const struct timespec until = ring_deadline(30.0);
     for (int m = 0; m < MAX_MEMBERS; m++) {
-        if (g_writers[m] && png_writer_drain_for(g_writers[m], 30.0) != 0) {
-            fprintf(stderr, "fsea-fft-sweep: member %d's tile PNG was still being written after 30 s; leaving it\n", m);
+        if (g_writers[m] && png_writer_drain_until(g_writers[m], &until) != 0) {
+            fprintf(stderr, "fsea-fft-sweep: member %d's tile PNG was still being written 30 s after the fatal error; leaving it\n", m);
         }
     }
     exit(EXIT_FAILURE);

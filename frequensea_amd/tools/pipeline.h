@@ -43,21 +43,30 @@ static inline void ring_wait(slot_ring *r, int slot, int want_full) {
 }
 /* ring_wait with a deadline: 0 = the slot got there, -1 = it did not within `seconds` (the fatal paths: a process that is
  * about to exit must not wait for ever on a writer whose owner is gone) */
-static inline int ring_wait_for(slot_ring *r, int slot, int want_full, double seconds) {
+static inline struct timespec ring_deadline(double seconds) {
     struct timespec until;
     clock_gettime(CLOCK_REALTIME, &until);
+    if (seconds < 0) seconds = 0;
     until.tv_sec += (time_t)seconds;
     until.tv_nsec += (long)((seconds - (double)(time_t)seconds) * 1e9);
     if (until.tv_nsec >= 1000000000L) {
         until.tv_sec += 1;
         until.tv_nsec -= 1000000000L;
     }
+    return until;
+}
+/* the deadline is ABSOLUTE (CLOCK_REALTIME): one deadline can bound a whole sequence of waits */
+static inline int ring_wait_until(slot_ring *r, int slot, int want_full, const struct timespec *until) {
     int rc = 0;
     pthread_mutex_lock(&r->mu);
-    while (r->full[slot] != want_full && rc == 0) rc = pthread_cond_timedwait(&r->cv, &r->mu, &until);
+    while (r->full[slot] != want_full && rc == 0) rc = pthread_cond_timedwait(&r->cv, &r->mu, until);
     const int ok = r->full[slot] == want_full;
     pthread_mutex_unlock(&r->mu);
     return ok ? 0 : -1;
+}
+static inline int ring_wait_for(slot_ring *r, int slot, int want_full, double seconds) {
+    const struct timespec until = ring_deadline(seconds);
+    return ring_wait_until(r, slot, want_full, &until);
 }
 static inline void ring_set(slot_ring *r, int slot, int full) {
     pthread_mutex_lock(&r->mu);
@@ -180,10 +189,14 @@ static inline void png_writer_drain(png_writer *w) {
     ring_wait(&w->ring, 1, 0);
 }
 /* the same with a bound on the wait; -1 = a PNG was still pending after `seconds` */
-static inline int png_writer_drain_for(png_writer *w, double seconds) {
-    const int a = ring_wait_for(&w->ring, 0, 0, seconds);
-    const int b = ring_wait_for(&w->ring, 1, 0, seconds);
+static inline int png_writer_drain_until(png_writer *w, const struct timespec *until) {
+    const int a = ring_wait_until(&w->ring, 0, 0, until);
+    const int b = ring_wait_until(&w->ring, 1, 0, until);
     return (a == 0 && b == 0) ? 0 : -1;
+}
+static inline int png_writer_drain_for(png_writer *w, double seconds) {
+    const struct timespec until = ring_deadline(seconds);   /* one deadline for both slots */
+    return png_writer_drain_until(w, &until);
 }
 /* waits for every submitted PNG; returns non-zero if one of them could not be written */
 static inline int png_writer_finish(png_writer *w) {

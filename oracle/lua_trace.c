@@ -421,7 +421,21 @@ int main(int argc, char **argv) {
         return 2;
     }
     lua_State *L = luaL_newstate();
-    luaL_openlibs(L);
+    /* The scenes are the reference's files: upstream, untrusted content run in the build container.  They need
+     * arithmetic, strings and tables; they get those and nothing that reaches the file system or a process: no io, os,
+     * package (require / loadlib) or debug library, and the base library's file loaders are removed.  main() below loads
+     * the two files itself through the C API. */
+    static const luaL_Reg safe_libs[] = {{"_G", luaopen_base},         {LUA_TABLIBNAME, luaopen_table}, {LUA_STRLIBNAME, luaopen_string},
+                                         {LUA_MATHLIBNAME, luaopen_math}, {LUA_UTF8LIBNAME, luaopen_utf8}, {NULL, NULL}};
+    for (const luaL_Reg *lib = safe_libs; lib->func; lib++) {
+        luaL_requiref(L, lib->name, lib->func, 1);
+        lua_pop(L, 1);
+    }
+    static const char *const removed[] = {"dofile", "loadfile", "load", "loadstring", "require", NULL};
+    for (int k = 0; removed[k]; k++) {
+        lua_pushnil(L);
+        lua_setglobal(L, removed[k]);
+    }
     regtype(L, "nut_buffer", gc_buffer);
     regtype(L, "nrf_device", NULL);
     regtype(L, "nrf_fft", NULL);

@@ -115,7 +115,8 @@ def test_a_hard_failure_behind_the_headline_still_leaves_the_line(mode):
 MULTI_GPU_KEYS = ("broad_sweep_ms_resident", "broad_sweep_ms_ingest", "stft_stream_ms", "regime", "gather_chunks",
                   "gather_backend", "rccl_world", "broad_sweep_resident_gathered_checksum_ok",
                   "broad_sweep_ingest_gathered_checksum_ok", "stft_stream_gathered_checksum_ok", "gather_gbps_per_link",
-                  "multi_gpu_error", "distinct_gpus", "rank_devices")
+                  "multi_gpu_error", "distinct_gpus", "rank_devices", "broad_sweep_resident_gathered_checksum_matches_pinned",
+                  "broad_sweep_ingest_gathered_checksum_matches_pinned", "stft_stream_gathered_checksum_matches_pinned")
 
 
 @pytest.mark.gpu
@@ -144,6 +145,10 @@ def test_bench_with_two_ranks_runs_the_sharded_sweep_and_stream_with_a_gather():
     assert ex["gather_gbps_per_link"] > 0 and ex["gather_bytes_per_peer"] == 256 * 256 * 4096
     assert "resident" in ex["regime"]["broad_sweep_ms_resident"] and "ingest" in ex["regime"]["broad_sweep_ms_ingest"]
     assert ex["broad_sweep_resident_gathered_checksum"] == ex["broad_sweep_ingest_gathered_checksum"]
+    # what arrived on rank 0 is the image tests/test_gpu_bench_jobs.py compared with the oracle (tests/golden/bench_job_checksums.json)
+    assert ex["broad_sweep_resident_gathered_checksum_matches_pinned"] is True
+    assert ex["broad_sweep_ingest_gathered_checksum_matches_pinned"] is True
+    assert ex["stft_stream_gathered_checksum_matches_pinned"] is None      # --stream-frames 4095: no constant for that length
     _same_image_at_every_world_size(2, ex["broad_sweep_resident_gathered_checksum"])
 
 
@@ -218,6 +223,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert ex["multi_gpu_error"] is None and ex["rccl_world"] == 1 and ex["gather_gbps_per_link"] is None
     assert ex["broad_sweep_resident_gathered_checksum_ok"] is True and ex["stft_stream_gathered_checksum_ok"] is True
     assert abs(ex["broad_sweep_ms_resident"] - ex["broad_sweep_1gpu_ms"]) < 1e-12 and ex["broad_sweep_ms_ingest"] > ex["broad_sweep_ms_resident"]
+    assert ex["broad_sweep_resident_gathered_checksum_matches_pinned"] is True and ex["stft_stream_gathered_checksum_matches_pinned"] is True
     _same_image_at_every_world_size(1, ex["broad_sweep_resident_gathered_checksum"])
     # independent batches on two streams: one launch's drain under the next one's ramp; beside `value`, never in it
     assert 0.9 * d["value"] < ex["two_stream_frames_per_sec_n8192"] < 1.3 * d["value_events"]

@@ -1572,10 +1572,20 @@ def test_launches_can_be_captured_into_a_hip_graph():
 def test_captured_streams_give_their_counter_slot_back():
     """A captured launch reserves its stream's ticket-counter slot (the graph's kernel node holds the address).  An
     application that captures on short-lived streams hands each slot back with fsea_plan_release_stream once the graph is
-    gone (ADVICE r05): 80 capture / replay / release rounds on one plan (64 slots) all work and give the direct rows;
-    without the release the plan runs out and says which call frees them."""
+    gone: 80 capture / replay / release rounds on 80 distinct streams of one plan (64 slots) all work and give
+    the direct rows; without the release the plan runs out at the 65th and says which call frees them.  (Streams from
+    fsea_stream_create: torch.cuda.Stream() hands out 32 pooled handles round-robin.)"""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda", 0)
+    L = fsea.hip_lib()
+    L.fsea_stream_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    L.fsea_stream_destroy.argtypes = [ctypes.c_int, ctypes.c_void_p]
+
+    def new_stream():
+        h = ctypes.c_void_p()
+        fsea._check(L.fsea_stream_create(0, ctypes.byref(h)))
+        return h.value, torch.cuda.ExternalStream(h.value, device=dev)
+
     n, nf = 8192, 96
     iq = torch.from_numpy(synth_iq(83, 2 * nf * n).copy()).to(dev)
     out = torch.zeros(nf * n, dtype=torch.float32, device=dev)
@@ -1584,8 +1594,10 @@ def test_captured_streams_give_their_counter_slot_back():
     plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     want = out.clone()
+    seen = set()
     for rnd in range(80):
-        side = torch.cuda.Stream()
+        handle, side = new_stream()
+        seen.add(handle)
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
@@ -1595,7 +1607,9 @@ def test_captured_streams_give_their_counter_slot_back():
         torch.cuda.synchronize()
         assert torch.equal(out, want), rnd
         del graph
-        plan.release_stream(side.cuda_stream)
+        plan.release_stream(handle)
+        del side
+        fsea._check(L.fsea_stream_destroy(0, handle))
     plan.release_stream(0)                                  # a stream without a slot: nothing to do, FSEA_OK
     plan.close()
     plan = fsea.Plan(n)
@@ -1603,19 +1617,25 @@ def test_captured_streams_give_their_counter_slot_back():
     keep = []
     with pytest.raises(fsea.FseaError, match="fsea_plan_release_stream"):
         for rnd in range(70):
-            side = torch.cuda.Stream()
+            handle, side = new_stream()
+            keep.append((handle, side))
             side.wait_stream(torch.cuda.current_stream())
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
                 plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
-            keep.append((side, graph))
+            keep[-1] += (graph,)
+    assert len(keep) == 65                                  # 64 slots held by captured streams, the 65th is refused
     torch.cuda.synchronize()
-    del keep
-    plan.reset()
+    plan.release_stream(keep[0][0])                         # one slot back: the next launch finds it
     plan.exec_device(iq.data_ptr(), nf, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+    handles = [k[0] for k in keep]
+    del keep, graph, side
+    plan.reset()
     plan.close()
+    for h in handles:
+        fsea._check(L.fsea_stream_destroy(0, h))
 
 
 def test_windowed_launches_capture_too_and_the_anysize_paths_refuse_a_capturing_stream():
