@@ -600,6 +600,12 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup, keep=None):
     for _ in range(max(warmup, 1)):
         step()
     torch.cuda.synchronize()
+    # clock pre-warm, as for the sweep (untimed; one GPU only: with peers the steps carry collectives)
+    t_pre = time.perf_counter()
+    while world == 1 and time.perf_counter() - t_pre < min(getattr(args, "prewarm", 0.25), 0.25):
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
@@ -611,13 +617,23 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup, keep=None):
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    k0.record()
-    for _ in range(5):
+    # the FFT kernel alone on this rank's shard, WARM: round 5 timed 5 launches straight after the barrier from a chip that
+    # had idled through the host-side bookkeeping and reported 0.387 of the roofline for a kernel that runs at 0.45 once the
+    # clock has settled (profiles/r06_stft_stream_shape.txt: cold 0.35-0.37, warm 0.45-0.47, however the stream is cut)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < min(getattr(args, "prewarm", 0.25), 0.25):
         plan.exec_device(iq.data_ptr(), f_hi - f_lo, rows.data_ptr(), flip=True, stream=stream)
-    k1.record()
-    torch.cuda.synchronize()
-    kernel_ms = k0.elapsed_time(k1) / 5
+        torch.cuda.synchronize()
+    kms = []
+    for _ in range(3):
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for _ in range(5):
+            plan.exec_device(iq.data_ptr(), f_hi - f_lo, rows.data_ptr(), flip=True, stream=stream)
+        k1.record()
+        torch.cuda.synchronize()
+        kms.append(k0.elapsed_time(k1) / 5)
+    kernel_ms = float(np.median(kms))
     if dist is not None:
         tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -655,7 +671,7 @@ def run_stft_stream(args, rank, world, dist, torch, steps, warmup, keep=None):
                                (total_frames, "%s taper fused into pass 0" % args.window if args.window else "rectangular frames"),
                    "window": args.window or "rectangular (the reference)",
                    "regime": "resident: every rank's samples (frames + 8192-sample halo) are in HBM when the step starts",
-                   "gather_chunks": n_chunks,
+                   "gather_chunks": n_chunks, "clock_prewarm_s": min(getattr(args, "prewarm", 0.25), 0.25) if world == 1 else 0.0,
                    "parallelism": "frame ranges x%d with an N - hop halo read redundantly, rows gathered by grouped send/recv" % world},
         "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
