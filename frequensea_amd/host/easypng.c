@@ -2,7 +2,7 @@
  * easypng.c -- 8-bit gray PNG writer / reader on zlib (include/easypng.h).
  * Writer: IHDR (8-bit, colour type 0, no interlace), one IDAT of the zlib-compressed
  * scanlines (filter type 0), IEND; what c/easypng.h:6-53 asks libpng for.  Large images are
- * deflated in up to eight slabs of rows on as many threads (one zlib stream, see deflate_slab).
+ * deflated in up to sixteen slabs of rows on as many threads (one zlib stream, see deflate_slab).
  * Reader: all five scanline filters, colour types 0/2/4/6 at 8 bits, converted to gray with
  * stb_image's integer luma (77 r + 150 g + 29 b) >> 8, as c/fft-stitch.c:172 requests.
  */
@@ -135,7 +135,7 @@ static int idat_put(idat_stream *st, const uint8_t *data, size_t len) {
     return 0;
 }
 
-#define PNG_MAX_SLABS 8
+#define PNG_MAX_SLABS 16
 #define PNG_SLAB_MIN_BYTES ((size_t)1 << 18) /* bytes per slab at least: smaller images are one slab, compressed on the calling thread */
 
 int write_gray_png(const char *fname, int width, int height, const uint8_t *buffer) {

@@ -14,6 +14,7 @@
  * usage: fsea-fft-stitch [--broad] --start MHZ --end MHZ [--step MHZ] [--rows H] [--footer F] [--dir DIR]
  *                        [--device D]
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,6 +22,54 @@
 #include "easypng.h"
 #include "fsea.h"
 #include "imgaxis.h"
+
+/* Tile PNGs are decoded ahead of the composite loop by a few threads: at the reference's own geometry (c/fft-stitch.c:16-27:
+ * 300 tiles of 1024 x 16384) the inflate of one tile takes longer than its upload + max-composite on the GPU, and 300 of
+ * them one after the other were two thirds of the tool's wall time (profiles/r06_reference_geometry_narrow.json).
+ * Decoder t takes tiles t, t + DECODERS, ...; the main thread consumes them in tile order. */
+#define DECODERS 8
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int full[DECODERS];
+    uint8_t *tile[DECODERS];
+    int w[DECODERS], h[DECODERS];
+    uint32_t n_tiles;
+    int broad;
+    double start, step;
+    const char *dir;
+} tile_queue;
+typedef struct {
+    tile_queue *q;
+    int slot;
+} decoder_arg;
+
+static void tile_name(const tile_queue *q, uint32_t k, char *file_name, size_t cap) {
+    const double f = q->start + k * q->step;
+    if (q->broad) snprintf(file_name, cap, "%s/broad-%.0f.png", q->dir, f);
+    else snprintf(file_name, cap, "%s/fft-%.4f.png", q->dir, f);
+}
+
+static void *decoder_main(void *p) {
+    const decoder_arg *a = (const decoder_arg *)p;
+    tile_queue *q = a->q;
+    const int s = a->slot;
+    for (uint32_t k = (uint32_t)s; k < q->n_tiles; k += DECODERS) {
+        char file_name[512];
+        tile_name(q, k, file_name, sizeof(file_name));
+        int w = 0, h = 0;
+        uint8_t *tile = read_gray_png(file_name, &w, &h); /* NULL = could not load: the main thread reports it in order */
+        pthread_mutex_lock(&q->mu);
+        while (q->full[s]) pthread_cond_wait(&q->cv, &q->mu);
+        q->tile[s] = tile;
+        q->w[s] = w;
+        q->h[s] = h;
+        q->full[s] = 1;
+        pthread_cond_broadcast(&q->cv);
+        pthread_mutex_unlock(&q->mu);
+    }
+    return NULL;
+}
 
 static void die(const char *what) {
     fprintf(stderr, "fsea-fft-stitch: %s: %s\n", what, fsea_last_error_string());
@@ -64,14 +113,39 @@ int main(int argc, char **argv) {
     void *d_image = NULL, *d_tile = NULL;
     size_t tile_cap = 0;
 
+    tile_queue queue;
+    memset(&queue, 0, sizeof(queue));
+    pthread_mutex_init(&queue.mu, NULL);
+    pthread_cond_init(&queue.cv, NULL);
+    queue.n_tiles = n_tiles;
+    queue.broad = broad;
+    queue.start = start;
+    queue.step = step;
+    queue.dir = dir;
+    pthread_t decoders[DECODERS];
+    decoder_arg decoder_args[DECODERS];
+    for (int t = 0; t < DECODERS && (uint32_t)t < n_tiles; t++) {
+        decoder_args[t].q = &queue;
+        decoder_args[t].slot = t;
+        if (pthread_create(&decoders[t], NULL, decoder_main, &decoder_args[t]) != 0) {
+            fprintf(stderr, "fsea-fft-stitch: cannot start a decoder thread\n");
+            return EXIT_FAILURE;
+        }
+        pthread_detach(decoders[t]); /* an error below ends the process; nothing joins them */
+    }
+
     for (uint32_t k = 0; k < n_tiles; k++) {
-        const double f = start + k * step;
         char file_name[512];
-        if (broad) snprintf(file_name, sizeof(file_name), "%s/broad-%.0f.png", dir, f);
-        else snprintf(file_name, sizeof(file_name), "%s/fft-%.4f.png", dir, f);
+        tile_name(&queue, k, file_name, sizeof(file_name));
         printf("Composing %s...\n", file_name);
-        int w = 0, h = 0;
-        uint8_t *tile = read_gray_png(file_name, &w, &h);
+        const int slot = (int)(k % DECODERS);
+        pthread_mutex_lock(&queue.mu);
+        while (!queue.full[slot]) pthread_cond_wait(&queue.cv, &queue.mu);
+        uint8_t *tile = queue.tile[slot];
+        const int w = queue.w[slot], h = queue.h[slot];
+        queue.full[slot] = 0; /* the decoder may fetch tile k + DECODERS */
+        pthread_cond_broadcast(&queue.cv);
+        pthread_mutex_unlock(&queue.mu);
         if (!tile) {
             fprintf(stderr, "ERROR: could not load %s\n", file_name);
             return EXIT_FAILURE;
