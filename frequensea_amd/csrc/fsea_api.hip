@@ -804,6 +804,8 @@ int fsea_plan_set_window(fsea_plan *p, const float *w) {
     FSEA_HIP(hipMemcpy(p->d_win, perm.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     FSEA_HIP(hipMemcpy(p->d_win_dc, dc.data(), dc.size() * sizeof(fsea::cf), hipMemcpyHostToDevice));
     p->window_form = form;
+    // computed once: everything pow2_kernel_name reads (entry, mode, hop, no_half_overlap) is fixed at plan creation
+    // (FSEA_NO_HALF_OVERLAP is read there, not per launch), so the windowed name cannot go stale
     if (p->kernel_name_win.empty()) p->kernel_name_win = pow2_kernel_name(p);
     return FSEA_OK;
 }
