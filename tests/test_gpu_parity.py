@@ -1212,7 +1212,10 @@ def test_config_c4_broad_sweep_at_full_size():
     """BASELINE config 4 on one GPU at its full size: 512 centre frequencies x 256 frames x 4096 points
     -> u8 dB tiles (DB5 + DC fix) -> stitched 256 x 2 097 152 image (c/fft-stitch-broad.c geometry).
     EVERY row of every tile against the oracle (the captures repeat with a period of 8192 frames: the oracle transforms
-    one period on the host's cores, all sixteen repetitions are compared with it), and the stitch against the tile stack."""
+    one period on the host's cores, all sixteen repetitions are compared with it), and the stitch against the tile stack.
+    (Periodic content: the geometry at full size, not the bench's workload.  bench.py's own config-4 job -- 512 captures seeded
+    4 000 000 + f, no repetition -- is compared with the oracle row by row in tests/test_gpu_bench_jobs.py, and so is config 5's
+    32767-frame stream.)"""
     n, rows, tiles = 4096, 256, 512
     chunk = synth_iq(4, 1 << 26)                              # 8192 frames of IQ, repeated 16 times = 1 GiB
     d_in = _repeat_upload(chunk, 16)
