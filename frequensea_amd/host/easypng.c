@@ -40,7 +40,8 @@ static int write_chunk(FILE *fp, const char *type, const uint8_t *data, uint32_t
 /* One slab of scanlines, compressed on its own thread as a raw deflate stream that ends on a byte boundary
  * (Z_FULL_FLUSH; the last slab finishes the stream), so that the slabs' outputs concatenate into ONE valid deflate stream
  * -- the way pigz writes.  A 1024 x 16384 tile (c/fft-batch.c's geometry) took 0.36 s to deflate on one core, a hundred
- * times the GPU's share of that capture; eight slabs take it to a few tens of milliseconds. */
+ * times the GPU's share of that capture; sixteen slabs take it to a few tens of milliseconds (eight until round 6: at the
+ * reference's own sweep geometry the encode was the stage the other two waited for, profiles/r06_reference_geometry_narrow.json). */
 typedef struct {
     const uint8_t *pixels; /* first row of the slab */
     int width, rows, last;

@@ -234,7 +234,7 @@ def test_replay_device_missing_file_is_zero_block():
 
 
 def test_png_writer_deflates_large_images_in_slabs(tmp_path):
-    """Images of a MiB and more are deflated as up to eight slabs of rows on as many threads, concatenated into one zlib
+    """Images of a MiB and more are deflated as up to sixteen slabs of rows on as many threads, concatenated into one zlib
     stream (host/easypng.c): ragged slab heights, compressible and incompressible content; decoded by PIL, by this
     library's reader and by zlib itself (one stream, correct Adler-32)."""
     import struct
