@@ -48,6 +48,8 @@ typedef struct {
     uint8_t *out;
     size_t out_len, out_cap;
     uLong adler; /* of the slab's raw bytes (filter bytes included) */
+    uLong out_crc; /* crc32 of the slab's compressed bytes, summed on the slab's own thread: the IDAT chunk's CRC is combined
+                      from these instead of one serial pass over the whole stream (a third of a 16 MiB tile's encode time) */
     size_t raw_len;
     int ok;
 } png_slab;
@@ -85,6 +87,12 @@ static void *deflate_slab(void *p) {
         const int rc = deflate(&zs, sl->last ? Z_FINISH : Z_FULL_FLUSH);
         if ((sl->last ? rc == Z_STREAM_END : rc == Z_OK) && zs.avail_in == 0) {
             sl->out_len = sl->out_cap - zs.avail_out;
+            sl->out_crc = crc32(0L, Z_NULL, 0);
+            for (size_t off = 0; off < sl->out_len;) {
+                const size_t piece = sl->out_len - off < ((size_t)1 << 30) ? sl->out_len - off : ((size_t)1 << 30);
+                sl->out_crc = crc32(sl->out_crc, sl->out + off, (uInt)piece);
+                off += piece;
+            }
             sl->ok = 1;
         }
         deflateEnd(&zs);
@@ -107,7 +115,9 @@ typedef struct {
     uLong crc;
 } idat_stream;
 
-static int idat_put(idat_stream *st, const uint8_t *data, size_t len) {
+/* `known_crc`: crc32 of data[0..len) computed elsewhere (a slab's own thread), or NULL.  Used when the whole piece falls into
+ * the open chunk (crc32_combine is O(log len)); a piece that a chunk boundary cuts is summed here byte by byte. */
+static int idat_put_crc(idat_stream *st, const uint8_t *data, size_t len, const uLong *known_crc) {
     while (len > 0) {
         if (st->in_chunk == 0) {
             if (st->left == 0) return -1;
@@ -121,11 +131,16 @@ static int idat_put(idat_stream *st, const uint8_t *data, size_t len) {
         }
         size_t n = len < st->in_chunk ? len : st->in_chunk;
         if (n > st->left) return -1;
-        /* crc32 takes a uInt length */
-        for (size_t off = 0; off < n;) {
-            const size_t piece = n - off < ((size_t)1 << 30) ? n - off : ((size_t)1 << 30);
-            st->crc = crc32(st->crc, data + off, (uInt)piece);
-            off += piece;
+        if (known_crc != NULL && n == len && len <= 0x7fffffffu) {
+            st->crc = crc32_combine(st->crc, *known_crc, (z_off_t)len);
+            known_crc = NULL;
+        } else {
+            known_crc = NULL; /* the piece is cut by a chunk boundary: its own sum no longer applies */
+            for (size_t off = 0; off < n;) { /* crc32 takes a uInt length */
+                const size_t piece = n - off < ((size_t)1 << 30) ? n - off : ((size_t)1 << 30);
+                st->crc = crc32(st->crc, data + off, (uInt)piece);
+                off += piece;
+            }
         }
         if (fwrite(data, 1, n, st->fp) != n) return -1;
         data += n;
@@ -140,6 +155,8 @@ static int idat_put(idat_stream *st, const uint8_t *data, size_t len) {
     }
     return 0;
 }
+
+static int idat_put(idat_stream *st, const uint8_t *data, size_t len) { return idat_put_crc(st, data, len, NULL); }
 
 #define PNG_MAX_SLABS 16
 #define PNG_SLAB_MIN_BYTES ((size_t)1 << 16) /* bytes per slab at least: smaller images are one slab, compressed on the calling thread */
@@ -214,7 +231,7 @@ int write_gray_png_chunked(const char *fname, int width, int height, const uint8
         st.left = 2 + 4;
         for (int k = 0; k < n_slabs; k++) st.left += slabs[k].out_len;
         int ok = fwrite(sig, 1, 8, fp) == 8 && write_chunk(fp, "IHDR", ihdr, 13) == 0 && idat_put(&st, zhead, 2) == 0;
-        for (int k = 0; ok && k < n_slabs; k++) ok = idat_put(&st, slabs[k].out, slabs[k].out_len) == 0;
+        for (int k = 0; ok && k < n_slabs; k++) ok = idat_put_crc(&st, slabs[k].out, slabs[k].out_len, &slabs[k].out_crc) == 0;
         ok = ok && idat_put(&st, ztail, 4) == 0 && st.left == 0 && st.in_chunk == 0;
         if (ok && write_chunk(fp, "IEND", NULL, 0) == 0) rc = 0;
     }
