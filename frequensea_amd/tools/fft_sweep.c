@@ -26,11 +26,15 @@
  *             position k is placed at x = k * FFT_SIZE / (SAMPLE_RATE / FREQUENCY_STEP)
  *   --chunk   tiles per gather (default 4)
  */
+#include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 
 #include "easypng.h"
 #include "fsea.h"
@@ -129,31 +133,43 @@ static int parse_devices(const char *text, int *devices) {
 /* rows of one capture, newest first: row y <- first 2N bytes of transfer skip + rows - 1 - y (c/fft-batch.c:62-74) */
 static int load_capture(const sweep_config *cfg, const capture *cap, uint8_t *packed, int *rows_out) {
     const size_t row_in = (size_t)2 * (size_t)cfg->fft_size;
-    FILE *fp = fopen(cap->path, "rb");
-    if (!fp) {
+    /* one pread per row, as fsea-fft-batch reads (a row is the first 2N bytes of a 262144-byte transfer) */
+    const int fd = open(cap->path, O_RDONLY);
+    if (fd < 0) {
         fprintf(stderr, "fsea-fft-sweep: cannot open %s\n", cap->path);
         return -1;
     }
-    fseek(fp, 0L, SEEK_END);
-    const long transfers = ftell(fp) / TRANSFER_BYTES;
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        fprintf(stderr, "fsea-fft-sweep: cannot stat %s\n", cap->path);
+        close(fd);
+        return -1;
+    }
+    const long transfers = (long)(st.st_size / TRANSFER_BYTES);
     int rows = (int)(transfers - cfg->skip);
     if (rows > cfg->rows_wanted) rows = cfg->rows_wanted;
     if (rows < cfg->rows_wanted) {
         fprintf(stderr, "fsea-fft-sweep: %s holds %ld transfers, need %d after skipping %d\n", cap->path, transfers,
                 cfg->rows_wanted, cfg->skip);
-        fclose(fp);
+        close(fd);
         return -1;
     }
     for (int y = 0; y < rows; y++) {
-        const long tr = (long)cfg->skip + rows - 1 - y;
-        fseek(fp, tr * (long)TRANSFER_BYTES, SEEK_SET);
-        if (fread(packed + (size_t)y * row_in, 1, row_in, fp) != row_in) {
+        const off_t tr = (off_t)cfg->skip + rows - 1 - y;
+        uint8_t *dst = packed + (size_t)y * row_in;
+        size_t got = 0;
+        while (got < row_in) {
+            const ssize_t r = pread(fd, dst + got, row_in - got, tr * (off_t)TRANSFER_BYTES + (off_t)got);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        if (got != row_in) {
             fprintf(stderr, "Short read, samples lost, exiting!\n");
-            fclose(fp);
+            close(fd);
             return -1;
         }
     }
-    fclose(fp);
+    close(fd);
     *rows_out = rows;
     return 0;
 }
