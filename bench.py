@@ -12,6 +12,11 @@ launched by torch.distributed.run) every rank transforms its own batch -- whole 
 across GPUs with no data-path collective -- and `value` is the aggregate over all ranks (weak
 scaling).  Rank 0 prints ONE JSON line.
 
+How the timed region is taken: an untimed clock-settle loop (64-launch blocks until three consecutive block times agree within
+1 %, at most --prewarm seconds; config.clock_prewarm_s), the W warm-up steps, barrier + synchronise, then EXACTLY K timed steps,
+synchronise + barrier: `value` / `ms_per_step` / `roofline` are that FIRST region.  --regions (9) identical regions follow it and
+are reported beside it (headline_regions_ms, official_over_median): how representative the one graded sample was.
+
 Extra objects on that line:
   roofline      dominant kernel vs the HBM roofline: algorithmic bytes per launch
                 (2*hop + 4*N per frame) / average launch duration measured with HIP events on
