@@ -1364,10 +1364,10 @@ def emit_line(line, rank):
                     g.stdin.write("FINAL " + text + "\n")
                     g.stdin.flush()
                     g.stdin.close()
-                    g.wait(timeout=20)
-                    return
+                    if g.wait(timeout=20) == 0:
+                        return
                 except Exception:
-                    pass                                         # the guardian is gone: print here
+                    pass                                         # the guardian is gone (or failed): print here
             print(text)
             sys.stdout.flush()
 
