@@ -339,3 +339,60 @@ def test_windowed_shifted_and_f64_rows_reduce_to_their_unwindowed_forms():
     w = O.window("hann", n)
     z = (x[0::2] + 1j * x[1::2]).reshape(nf, n) * ((-1.0) ** np.arange(n)) * w
     assert np.max(np.abs(O.rows_f64(x, nf, n, mode=O.MODE_COMPLEX, window=w) - np.fft.fft(z, axis=1))) < 1e-10
+
+
+def _numpy_rows(raw, n_frames, n, hop, flip, mode):
+    """An independent restatement in numpy (pocketfft, f64) of what O.rows computes: src/nrf.c:95-110 (flip), :599-614 (unpack +
+    (-1)^n), :615 (forward DFT), :619-630 (magnitude + DC patch); c/fft-batch.c:83-94 and c/fft-batch-broad.c:106-121 (pixels)."""
+    sign = 1.0 - 2.0 * (np.arange(n) & 1)
+    out = []
+    for f in range(n_frames):
+        b = raw[2 * f * hop: 2 * (f * hop + n)]
+        u = ((b.astype(np.int64) + 128) % 256 if flip else b.astype(np.int64)).astype(np.float64) / 256.0
+        spec = np.fft.fft((u[0::2] + 1j * u[1::2]) * sign)
+        if mode == O.MODE_MAG:
+            row = np.abs(spec)
+            row[n // 2] = row[n // 2 - 1]
+        elif mode == O.MODE_MAG_NODC:
+            row = np.abs(spec)
+        elif mode == O.MODE_COMPLEX:
+            row = spec
+        else:
+            scale = 10.0 if mode == O.MODE_DB10_U8 else 5.0
+            d = 10.0 * np.log10(spec.real ** 2 + spec.imag ** 2 + 1e-20) * scale
+            row = np.clip(np.trunc(d), 0, 255)
+            if mode == O.MODE_DB5_U8_DCFIX:
+                row[n // 2] = row[n // 2 - 1]
+        out.append(row)
+    return np.stack(out)
+
+
+def test_rows_of_random_geometry_against_an_independent_numpy_restatement():
+    """Beyond the fixed fixtures: sizes, frame counts, hops (overlapped, gapped), both byte conventions and every epilogue drawn
+    at random (hypothesis), the oracle's C loop against numpy's pocketfft with the epilogues written out again -- frame
+    indexing, flip, centring, DC patch, truncation and clamp.  Pixels may differ where the dB value sits within 1e-9 of an
+    integer (two f64 FFTs round differently there); nowhere else."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None, derandomize=True)
+    @given(st.sampled_from([32, 64, 128, 256, 512, 1024, 2048, 4096]), st.integers(1, 9), st.sampled_from([0.5, 1.0, 1.25]),
+           st.booleans(), st.sampled_from([O.MODE_MAG, O.MODE_MAG_NODC, O.MODE_COMPLEX, O.MODE_DB10_U8, O.MODE_DB5_U8_DCFIX]),
+           st.integers(0, 2 ** 31 - 1))
+    def check(n, n_frames, hop_frac, flip, mode, seed):
+        hop = max(8, int(n * hop_frac) // 8 * 8)
+        rng = np.random.default_rng(seed)
+        raw = rng.integers(0, 256, 2 * ((n_frames - 1) * hop + n), dtype=np.uint8)
+        if seed % 5 == 0:
+            raw[:] = 0x80 if flip else 0x00                      # silence: log of (almost) nothing, the clamp at 0
+        got = O.rows(raw, n_frames, n, hop=hop, flip=flip, mode=mode)
+        want = _numpy_rows(raw, n_frames, n, hop, flip, mode)
+        if mode in (O.MODE_DB10_U8, O.MODE_DB5_U8_DCFIX):
+            diff = got.astype(np.int64) != want.astype(np.int64)
+            if diff.any():                                       # only at a truncation boundary
+                u = (raw.astype(np.int64) + 128) % 256 if flip else raw.astype(np.int64)
+                assert np.count_nonzero(diff) <= 2 and np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1, (n, hop, mode, u[:4])
+        else:
+            scale = max(1.0, float(np.abs(want).max()))
+            assert np.abs(got - want).max() <= 1e-11 * scale * np.log2(n), (n, n_frames, hop, flip, mode)
+
+    check()
