@@ -59,6 +59,7 @@ typedef struct {
 typedef struct {
     int id, n, h;
     double *history;
+    double *window; /* nrf_fft_set_window (this repository's addition, include/nrf.h): NULL = the reference's rectangular frames */
 } tfft;
 
 typedef struct {
@@ -272,12 +273,43 @@ static int l_fft_process(lua_State *L) {
         orc_unpack_center_f64(pad, (size_t)n, x);
         free(pad);
     }
+    if (f->window) { /* the taper beside the (-1)^ii of the unpack loop: x[ii] = (-1)^ii * w[ii] * value (orc_rows_windowed) */
+        for (int j = 0; j < n; j++) {
+            x[2 * j] *= f->window[j];
+            x[2 * j + 1] *= f->window[j];
+        }
+    }
     orc_fft_forward(x, spec, n);              /* 615 */
     orc_history_scroll(f->history, n, f->h);  /* 616-617 */
     orc_mag_row(spec, n, f->history);         /* 619-630 */
     free(x);
     free(spec);
     fprintf(g_out, "{\"ev\": \"call\", \"fn\": \"nrf_fft_process\", \"fft\": %d, \"buffer\": %d}\n", f->id, b->id);
+    return 0;
+}
+/* nrf_fft_set_window(fft, name): NOT a function of the reference (its scenes never call it); the binding INTEGRATION.md shows
+ * beside l_nrf_fft_shift, so that a scene written for this library (tests/golden/scenes/) can be traced like the reference's.
+ * The weights are the oracle's, rounded to float as the kernel holds them. */
+static int l_fft_set_window(lua_State *L) {
+    tfft *f = (tfft *)from_object(L, "nrf_fft", 1);
+    const char *name = luaL_checkstring(L, 2);
+    static const char *const names[] = {"rect", "hann", "hamming", "blackman", "blackmanharris", "flattop"};
+    int kind = -1;
+    for (int k = 0; k < 6; k++) {
+        if (!strcmp(name, names[k])) kind = k;
+    }
+    if (!strcmp(name, "none") || name[0] == '\0') kind = 0;
+    if (kind < 0) return luaL_error(L, "nrf_fft_set_window: unknown taper '%s'", name);
+    free(f->window);
+    f->window = NULL;
+    if (kind > 0) {
+        f->window = (double *)calloc((size_t)f->n, sizeof(double));
+        if (orc_window_fill(kind, f->n, f->window) != 0) return luaL_error(L, "nrf_fft_set_window: orc_window_fill failed");
+        for (int j = 0; j < f->n; j++) f->window[j] = (double)(float)f->window[j];
+    }
+    fprintf(g_out, "{\"ev\": \"call\", \"fn\": \"nrf_fft_set_window\", \"fft\": %d, \"name\": ", f->id);
+    jstr(name);
+    fprintf(g_out, "}\n");
     return 0;
 }
 static int l_fft_get_buffer(lua_State *L) {
@@ -399,12 +431,13 @@ static int call_global(lua_State *L, const char *name, int nargs) { /* src/main.
 }
 
 int main(int argc, char **argv) {
-    const char *lua_dir = NULL, *scene = NULL, *keys = "";
+    const char *lua_dir = NULL, *scene = NULL, *scene_path = NULL, *keys = "";
     int frames = 8;
     g_out = stdout;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--lua-dir") && i + 1 < argc) lua_dir = argv[++i];
         else if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene = argv[++i];
+        else if (!strcmp(argv[i], "--scene-path") && i + 1 < argc) scene_path = argv[++i]; /* a scene outside --lua-dir (this repository's own) */
         else if (!strcmp(argv[i], "--replay") && i + 1 < argc) g_replay = argv[++i];
         else if (!strcmp(argv[i], "--frames") && i + 1 < argc) frames = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--keys") && i + 1 < argc) keys = argv[++i];
@@ -447,6 +480,7 @@ int main(int argc, char **argv) {
     reg(L, "nrf_fft_shift", l_fft_shift);
     reg(L, "nrf_fft_process", l_fft_process);
     reg(L, "nrf_fft_get_buffer", l_fft_get_buffer);
+    reg(L, "nrf_fft_set_window", l_fft_set_window);
     reg(L, "nrf_freq_shifter_new", l_shifter_new);
     reg(L, "nrf_freq_shifter_process", l_shifter_process);
     reg(L, "nrf_freq_shifter_get_buffer", l_shifter_get_buffer);
@@ -477,7 +511,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "%s\n", lua_tostring(L, -1));
         return 1;
     }
-    snprintf(path, sizeof(path), "%s/%s", lua_dir, scene); /* 1248 */
+    if (scene_path) snprintf(path, sizeof(path), "%s", scene_path);
+    else snprintf(path, sizeof(path), "%s/%s", lua_dir, scene); /* 1248 */
     if (luaL_loadfile(L, path) || lua_pcall(L, 0, 0, 0)) {
         fprintf(stderr, "%s\n", lua_tostring(L, -1));
         return 1;

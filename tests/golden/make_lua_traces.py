@@ -51,6 +51,15 @@ RUNS = {
     "fft-sea-sick.lua": (7, "2:262:0,4:263:1"),
 }
 
+# THIS REPOSITORY'S scenes (tests/golden/scenes/, not the reference's): a scene that chooses its taper through
+# nrf_fft_set_window, the addition of include/nrf.h, traced under the same interpreter and host.  Kept apart in the file
+# ("own_scenes") so that "scenes" stays what the reference's five scripts do.
+# KEY_B 66 (Blackman-Harris), a retune (right), KEY_F 70 (flat top), KEY_R 82 (rectangular), KEY_H 72 (Hann again)
+OWN_SCENES_DIR = os.path.join(HERE, "scenes")
+OWN_RUNS = {
+    "fft-windowed.lua": (10, "3:66:0,5:262:0,6:70:0,8:82:0,9:72:0"),
+}
+
 
 def replay_blocks():
     g = np.load(os.path.join(HERE, "rfdata_golden.npz"))
@@ -71,10 +80,16 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         replay = os.path.join(tmp, "replay.raw")
         replay_blocks().tofile(replay)
-        for scene, (frames, keys) in RUNS.items():
+        out["own_scenes"] = {}
+        runs = [("scenes", scene, None, fk) for scene, fk in RUNS.items()]
+        runs += [("own_scenes", scene, os.path.join(OWN_SCENES_DIR, scene), fk) for scene, fk in OWN_RUNS.items()]
+        for group, scene, own_path, (frames, keys) in runs:
             trace = os.path.join(tmp, scene + ".jsonl")
-            r = subprocess.run([TRACER, "--lua-dir", REF_LUA, "--scene", scene, "--replay", replay, "--frames", str(frames),
-                                "--keys", keys, "--out", trace], capture_output=True, text=True)
+            cmd = [TRACER, "--lua-dir", REF_LUA, "--scene", scene, "--replay", replay, "--frames", str(frames), "--keys", keys,
+                   "--out", trace]
+            if own_path:
+                cmd += ["--scene-path", own_path]
+            r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 sys.exit("%s: lua_trace failed (%d)\n%s" % (scene, r.returncode, r.stderr))
             events, stubs = [], {}
@@ -87,7 +102,7 @@ def main():
                     ev["stubs"] = stubs
                     stubs = {}
                 events.append(ev)
-            out["scenes"][scene] = {"events": events, "script_output": r.stdout.splitlines()}
+            out[group][scene] = {"events": events, "script_output": r.stdout.splitlines()}
             calls = [e["fn"] for e in events if e["ev"] == "call"]
             print("%-18s %4d frames, %5d events: %s" % (scene, frames, len(events),
                   ", ".join("%s x%d" % (f, calls.count(f)) for f in sorted(set(calls)))))

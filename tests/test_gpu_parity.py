@@ -1369,6 +1369,9 @@ def _lua_traces():
 
 
 LUA_SCENES = ("fft.lua", "fft-shifted.lua", "fft-sea.lua", "fft-sea-auto.lua", "fft-sea-sick.lua")
+# this repository's own scene (tests/golden/scenes/, traced by the same host): two nrf_fft objects, one of which chooses and
+# changes its taper through nrf_fft_set_window (include/nrf.h: the addition beside the reference's five prototypes)
+OWN_LUA_SCENES = ("fft-windowed.lua",)
 
 
 def _num(v):
@@ -1402,11 +1405,12 @@ def scene_taper(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("scene", LUA_SCENES)
+@pytest.mark.parametrize("scene", LUA_SCENES + OWN_LUA_SCENES)
 def test_lua_scene_trace_replay(golden, tmp_path, scene, history_mode, scene_taper):
     import time
     traces = _lua_traces()
-    events = traces["scenes"][scene]["events"]
+    own = scene in OWN_LUA_SCENES
+    events = traces["own_scenes" if own else "scenes"][scene]["events"]
     L = nrf.nrf_lib()
     # the replay file the generator used: four blocks, the recorded captures' first 32 KiB, zero beyond
     blocks = []
@@ -1423,8 +1427,9 @@ def test_lua_scene_trace_replay(golden, tmp_path, scene, history_mode, scene_tap
     ffts, shifters, buffers = {}, {}, {}              # trace id -> our objects
     n_checked = {"get_buffer": 0, "texture": 0, "shift": 0}
 
-    def window_of(n):
-        return O.window(scene_taper, n).astype(np.float32).astype(np.float64) if scene_taper else None
+    def window_of(f):                                 # the taper this nrf_fft object carries right now (None = rectangular)
+        name = f["taper"]
+        return O.window(name, f["n"]).astype(np.float32).astype(np.float64) if name else None
 
     for ev in events:
         kind = ev["ev"]
@@ -1462,16 +1467,23 @@ def test_lua_scene_trace_replay(golden, tmp_path, scene, history_mode, scene_tap
             buffers[ev["ret"]["id"]] = {"ptr": samples, "u8": want}
         elif fn == "nrf_fft_new":
             n, h = ev["fft_size"], ev["fft_history_size"]
-            ffts[ev["ret"]] = {"ptr": L.nrf_fft_new(n, h), "n": n, "h": h, "want": np.zeros((h, n))}
+            # a new block starts from NRF_FFT_WINDOW (scene_taper); nrf_fft_set_window overrides it per object
+            ffts[ev["ret"]] = {"ptr": L.nrf_fft_new(n, h), "n": n, "h": h, "want": np.zeros((h, n)), "taper": scene_taper}
+        elif fn == "nrf_fft_set_window":
+            assert own, "the reference's scenes never call the addition"
+            f = ffts[ev["fft"]]
+            L.nrf_fft_set_window(f["ptr"], ev["name"].encode())
+            f["taper"] = None if ev["name"] in ("rect", "none", "") else ev["name"]
+            n_checked["set_window"] = n_checked.get("set_window", 0) + 1
         elif fn == "nrf_fft_process":
             f, b = ffts[ev["fft"]], buffers[ev["buffer"]]
             L.nrf_fft_process(f["ptr"], b["ptr"])
             n = f["n"]
             if "u8" in b:                             # src/nrf.c:603-606 (device buffers are offset binary already)
-                row = (O.rows_windowed(b["u8"][: 2 * n], 1, n, window_of(n), flip=False) if scene_taper
+                row = (O.rows_windowed(b["u8"][: 2 * n], 1, n, window_of(f), flip=False) if f["taper"]
                        else O.rows(b["u8"][: 2 * n], 1, n, flip=False))[0]
             else:                                     # src/nrf.c:607-612: the shifter's F64 output
-                row = O.rows_f64(b["f64"][: 2 * n], 1, n, window=window_of(n))[0]
+                row = O.rows_f64(b["f64"][: 2 * n], 1, n, window=window_of(f))[0]
             f["want"] = np.vstack([row[None, :], f["want"][:-1]])                 # src/nrf.c:616-617: newest row first
         elif fn == "nrf_fft_shift":
             f = ffts[ev["fft"]]
@@ -1522,7 +1534,8 @@ def test_lua_scene_trace_replay(golden, tmp_path, scene, history_mode, scene_tap
         else:
             raise AssertionError("trace names a call the replay does not know: %s" % fn)
     frames = sum(1 for e in events if e["ev"] == "frame")
-    assert n_checked["get_buffer"] == frames and n_checked["texture"] == frames and n_checked["shift"] >= 1
+    assert n_checked["get_buffer"] == frames * len(ffts) and n_checked["texture"] == frames and n_checked["shift"] >= 1
+    assert n_checked.get("set_window", 0) == (5 if own else 0)
     for b in buffers.values():
         L.nut_buffer_free(b["ptr"])
     for sh in shifters.values():

@@ -100,7 +100,8 @@ def _num(v):
 
 
 def test_committed_lua_traces_are_what_the_oracle_computes():
-    """tests/golden/lua_scene_traces.json without a GPU and without the reference: the five scenes are there, every call is
+    """tests/golden/lua_scene_traces.json without a GPU and without the reference: the five scenes (and this repository's own
+    windowed scene, apart from them) are there, every call is
     one the replay knows, nrf_fft_shift's d is the float the binding hands over (src/main.cpp:788), and the checksums the
     trace recorded for every fft_buffer are the ones the oracle gives for the same call sequence on the same blocks -- if the
     oracle changes, the traces have to be regenerated (tests/golden/make_lua_traces.py)."""
@@ -115,15 +116,23 @@ def test_committed_lua_traces_are_what_the_oracle_computes():
     known = {"nrf_device_new", "nrf_device_set_frequency", "nrf_device_get_samples_buffer", "nrf_fft_new", "nrf_fft_process",
              "nrf_fft_shift", "nrf_fft_get_buffer", "nrf_freq_shifter_new", "nrf_freq_shifter_process",
              "nrf_freq_shifter_get_buffer", "ngl_texture_update"}
-    for scene, body in traces["scenes"].items():
-        ffts, shifters, bufs = {}, {}, {}
+    # this repository's own scene (tests/golden/scenes/fft-windowed.lua): kept apart from the reference's five, and the only
+    # place where the taper addition of include/nrf.h may appear
+    assert sorted(traces["own_scenes"]) == ["fft-windowed.lua"]
+    for scene, body in list(traces["scenes"].items()) + list(traces["own_scenes"].items()):
+        own = scene in traces["own_scenes"]
+        ffts, shifters, bufs, windows = {}, {}, {}, {}
         seen = set()
         for ev in body["events"]:
             if ev["ev"] != "call":
                 continue
             fn = ev["fn"]
-            assert fn in known, (scene, fn)
+            assert fn in known or (own and fn == "nrf_fft_set_window"), (scene, fn)
             seen.add(fn)
+            if fn == "nrf_fft_set_window":
+                name = ev["name"]
+                windows[ev["fft"]] = None if name in ("rect", "none", "") else O.window(name, ffts[ev["fft"]][0]).astype(np.float32).astype(np.float64)
+                continue
             if fn == "nrf_device_get_samples_buffer":
                 bufs[ev["ret"]["id"]] = ("u8", blocks[ev["block"]])
             elif fn == "nrf_fft_new":
@@ -131,7 +140,11 @@ def test_committed_lua_traces_are_what_the_oracle_computes():
             elif fn == "nrf_fft_process":
                 n, h, hist = ffts[ev["fft"]]
                 kind, data = bufs[ev["buffer"]]
-                row = (O.rows(data[: 2 * n], 1, n, flip=False) if kind == "u8" else O.rows_f64(data[: 2 * n], 1, n))[0]
+                w = windows.get(ev["fft"])
+                if w is not None:
+                    row = (O.rows_windowed(data[: 2 * n], 1, n, w, flip=False) if kind == "u8" else O.rows_f64(data[: 2 * n], 1, n, window=w))[0]
+                else:
+                    row = (O.rows(data[: 2 * n], 1, n, flip=False) if kind == "u8" else O.rows_f64(data[: 2 * n], 1, n))[0]
                 ffts[ev["fft"]][2] = np.vstack([row[None, :], hist[:-1]])
             elif fn == "nrf_fft_shift":
                 assert _num(ev["d"]) == np.float32(_num(ev["d_lua"]))
@@ -160,6 +173,7 @@ def test_committed_lua_traces_are_what_the_oracle_computes():
                 assert abs(got - _num(ev["f32_sum"])) <= 1e-9 * max(1.0, abs(got))
         assert {"nrf_device_new", "nrf_fft_new", "nrf_fft_process", "nrf_fft_get_buffer", "nrf_fft_shift",
                 "ngl_texture_update"} <= seen, scene
+        assert ("nrf_fft_set_window" in seen) == own, scene          # the reference's scenes never call the addition
     # what the scripts do that a reading of them had missed (rounds 2-4 replayed a hand-written table)
     sea = [e for e in traces["scenes"]["fft-sea.lua"]["events"] if e["ev"] == "call" and e["fn"] == "nrf_fft_shift"]
     assert _num(sea[0]["d"]) == float("inf")                          # set_freq(freq) from setup(): d = 5 / 0
